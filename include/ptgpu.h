@@ -1,0 +1,206 @@
+/*
+ * ptgpu.h — C ABI of the MI355X (gfx950) render hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns 0
+ * on success or a negative PtStatus, and never lets an exception cross the
+ * boundary.  The text of the last failure on the calling thread is available
+ * from pt_last_error().
+ *
+ * The reference (kejcao/pathtracer @ 2024-10-08) has no FFI layer of its own.
+ * The two seams this library replaces are
+ *   Seam A  HitData Scene::castray(vec origin, vec direction) const   scene.cpp:18-20
+ *   Seam B  void Camera::render(const Scene&, int samples, cb)        camera.cpp:171-200
+ * and each declaration below cites the reference lines it stands in for.
+ *
+ * Threading: one host thread drives one PtScene at a time; distinct PtScene
+ * objects (also on distinct devices) may be driven concurrently.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PtStatus {
+  PT_OK = 0,
+  PT_ERR_INVALID = -1,   /* null pointer, inconsistent sizes, malformed tree */
+  PT_ERR_DEVICE = -2,    /* a HIP call failed; see pt_last_error() */
+  PT_ERR_NOMEM = -3,     /* host or device allocation failed */
+  PT_ERR_UNSUPPORTED = -4, /* e.g. tree deeper than the traversal stack */
+  PT_ERR_NODEVICE = -5   /* no gfx950 device / code object not loadable */
+} PtStatus;
+
+/*
+ * One BVH node exactly as the reference lays it out (BVH::Node, object.cpp:228-238):
+ * count == 0  -> internal node, children are nodes[index_or_first] and
+ *                nodes[index_or_first + 1];
+ * count  > 0  -> leaf over objects[index_or_first .. index_or_first + count).
+ * 32 bytes.
+ */
+typedef struct PtNode {
+  uint32_t index_or_first;
+  uint32_t count;
+  float bmin[3];
+  float bmax[3];
+} PtNode;
+
+/* Material fields the integrator reads (Material, object.cpp:144-156;
+ * read at camera.cpp:113,122,154).  Defaults in the reference: kd=.5, ke=0. */
+typedef struct PtMaterial {
+  float kd[3];
+  float ke[3];
+} PtMaterial;
+
+/*
+ * A whole scene as the reference holds it after Scene::Scene (scene.cpp:15):
+ * a top-level BVH over meshes (one Polygon per OBJ `o` group) and one private
+ * BVH per mesh over its triangles (object.cpp:497-503).  Meshes and triangles
+ * are given in creation ("file") order; the two `order` arrays are the
+ * permutations BVH::objects holds after BVH::subdivide (object.cpp:313-361).
+ * The library copies everything; the caller keeps ownership of these arrays.
+ */
+typedef struct PtSceneDesc {
+  uint32_t n_meshes;
+  uint32_t n_tris;               /* total over all meshes */
+  uint32_t n_materials;
+  uint32_t n_tlas_nodes;
+  const PtNode *tlas_nodes;      /* [n_tlas_nodes], node 0 is the root */
+  const uint32_t *tlas_order;    /* [n_meshes] slot in Scene::objects.objects -> mesh id */
+  const uint32_t *blas_node_offset; /* [n_meshes+1] start of each mesh's nodes in blas_nodes */
+  const PtNode *blas_nodes;      /* concatenated; index_or_first is local to the mesh */
+  const uint32_t *tri_offset;    /* [n_meshes+1] first global triangle id of each mesh */
+  const uint32_t *blas_order;    /* [n_tris] slot in the mesh's BVH::objects -> local triangle id */
+  const float *tri_verts;        /* [n_tris][3][3]: v0.xyz v1.xyz v2.xyz (Triangle::v0/v1/v2, object.cpp:529-540) */
+  const uint32_t *mesh_material; /* [n_meshes] index into materials */
+  const PtMaterial *materials;   /* [n_materials] */
+} PtSceneDesc;
+
+typedef struct PtScene PtScene; /* opaque; owns the device copies */
+
+typedef struct PtSceneInfo {
+  uint32_t n_meshes, n_tris, n_lights;
+  uint32_t n_wide_nodes;   /* 64-byte two-child device nodes */
+  uint32_t max_depth;      /* traversal stack entries the deepest ray can need */
+  uint32_t device;         /* HIP device ordinal the scene lives on */
+  uint64_t device_bytes;   /* bytes of HBM held by the scene */
+} PtSceneInfo;
+
+/* Camera state read by Camera::render (camera.cpp:49-58,161-169).  `euler` is
+ * Camera::direction (radians, rotate(a,b,y) of math.cpp:130-143).  aperture and
+ * focus are an extension (thin lens); aperture == 0 is the reference pinhole. */
+typedef struct PtCamera {
+  float origin[3];
+  float euler[3];
+  float fov_deg;   /* reference default 65 (camera.cpp:58) */
+  int32_t vw, vh;  /* reference default 1,1 (camera.cpp:55) */
+  float aperture;  /* lens radius; 0 = pinhole */
+  float focus;     /* distance of the plane in focus along camera z; used when aperture > 0 */
+} PtCamera;
+
+enum { PT_SAMPLE_UNIFORM = 0, PT_SAMPLE_COSINE = 1 };
+enum { PT_TRACE_EXACT = 0, PT_TRACE_FAST = 1 };
+
+/* Integrator constants.  pt_options_default() fills in the reference literals
+ * (camera.cpp:52,118-119,152). */
+typedef struct PtOptions {
+  float rr_prob;        /* 0.7 */
+  int32_t rr_min_depth; /* roulette only when depth > rr_min_depth; 2 */
+  int32_t max_depth;    /* 0 = unbounded (reference); k>0: a path has at most k vertices */
+  int32_t sampling;     /* PT_SAMPLE_UNIFORM (reference) or PT_SAMPLE_COSINE (extension) */
+  float bgcolor[3];     /* 0,0,0 */
+  int32_t trace_mode;   /* PT_TRACE_FAST (default) or PT_TRACE_EXACT */
+  uint32_t spp_stride;  /* sample k of this call has global index spp_begin + k*spp_stride; 1 */
+  uint32_t batch_spp;   /* samples per pixel kept in flight together; 0 = library picks */
+} PtOptions;
+
+/* Work counters of one render or trace call; all are sums over rays. */
+typedef struct PtCounters {
+  uint64_t paths;         /* camera paths started */
+  uint64_t rays_closest;  /* closest-hit queries (primary + bounce), camera.cpp:64 */
+  uint64_t rays_shadow;   /* visibility queries, camera.cpp:101 */
+  uint64_t node_boxes;    /* 32-byte node boxes tested (0 unless the library was built with counters) */
+  uint64_t tri_tests;     /* triangles tested (same) */
+  uint64_t bounce_passes; /* kernel passes over the path queue */
+} PtCounters;
+
+const char *pt_last_error(void);
+
+/* Number of usable devices, or a negative status. */
+int pt_device_count(void);
+
+void pt_options_default(PtOptions *opt);
+void pt_camera_default(PtCamera *cam);
+
+/* Replaces the per-frame state the reference keeps in `Scene` (scene.cpp:11-33):
+ * flattens both BVH levels into one device tree, orders triangle slots so that
+ * the slot index is the tie-break rank of BVH::intersect (object.cpp:265-285),
+ * and builds the light table of Scene::lights() (scene.cpp:22-30) with the
+ * areas of Triangle::area / Polygon::area (object.cpp:395-404,493-495). */
+int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out);
+void pt_scene_free(PtScene *scene);
+int pt_scene_info(const PtScene *scene, PtSceneInfo *info);
+
+/* Seam A, batched: result i equals Scene::castray((ox,oy,oz)[i], (dx,dy,dz)[i])
+ * (scene.cpp:18-20 -> object.cpp:265-285,406-429).  tri = global triangle id in
+ * file order, -1 and t = +INF on a miss; u, v are HitData::barycentric.x/.y.
+ * u and v may be null.  Host pointers; the call stages through HBM and waits. */
+int pt_trace_closest(PtScene *scene, size_t n,
+                     const float *ox, const float *oy, const float *oz,
+                     const float *dx, const float *dy, const float *dz,
+                     float *t, int32_t *tri, float *u, float *v, int mode);
+
+/* Same with device pointers on the scene's device; enqueues on `stream`
+ * (a hipStream_t, may be null) and does not wait. */
+int pt_trace_closest_dev(PtScene *scene, size_t n,
+                         const float *ox, const float *oy, const float *oz,
+                         const float *dx, const float *dy, const float *dz,
+                         float *t, int32_t *tri, float *u, float *v, int mode,
+                         void *stream);
+
+/* Visibility form of Seam A as camera.cpp:101 uses it:
+ * hit[i] = (Scene::castray(o,d).t != INF).  Host pointers. */
+int pt_trace_any(PtScene *scene, size_t n,
+                 const float *ox, const float *oy, const float *oz,
+                 const float *dx, const float *dy, const float *dz,
+                 uint8_t *hit, int mode);
+
+/* Camera::point_towards for every pixel (camera.cpp:161-169): dir[(py*W+px)*3+c].
+ * Host pointer. */
+int pt_camera_rays(const PtCamera *cam, int W, int H, int device, float *dir_xyz);
+
+/* Seam B (camera.cpp:171-200).  Renders samples spp_begin + k*spp_stride,
+ * k in [0, spp_count), of every pixel and ADDS their radiance to
+ * accum_rgb_sum[(py*W+px)*3+c] (host memory, W*H*3 floats).  The reference's
+ * Camera::pixels equals sum / total_spp * 255 (camera.cpp:188-190).
+ * Random numbers are a counter-based function of (seed, pixel, global sample
+ * index, draw index), so any split of the sample range over calls or devices
+ * gives the same per-sample radiance.  counters may be null. */
+int pt_render(PtScene *scene, const PtCamera *cam, int W, int H,
+              uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
+              const PtOptions *opt, float *accum_rgb_sum, PtCounters *counters);
+
+/* Same with accum_rgb_sum in device memory on the scene's device; kernels are
+ * enqueued on `stream`; the call returns after the last bounce pass has been
+ * counted (it reads one 4-byte counter per pass) but the final add into
+ * accum_rgb_sum may still be in flight on `stream`. */
+int pt_render_dev(PtScene *scene, const PtCamera *cam, int W, int H,
+                  uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
+                  const PtOptions *opt, float *accum_rgb_sum_dev,
+                  PtCounters *counters, void *stream);
+
+/* Resolve sums to the reference's pixel values: out = sum / spp * 255
+ * (camera.cpp:188-190), host memory, n floats. */
+int pt_resolve(const float *accum_rgb_sum, size_t n, uint32_t spp, float *pixels);
+
+/* The counter-based generator, exposed so that tests can pin it:
+ * Philox-4x32-10 with counter (c0,c1,c2,c3) and key (k0,k1). */
+void pt_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */
