@@ -144,6 +144,15 @@ int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out);
 void pt_scene_free(PtScene *scene);
 int pt_scene_info(const PtScene *scene, PtSceneInfo *info);
 
+/* Work counters (PtCounters.node_boxes / tri_tests): off by default.  When on,
+ * separately compiled counting kernels run instead of the plain ones.  They have
+ * no counterpart in the reference; HitData::hits (object.cpp:203) counts something
+ * else (internal nodes above the winning leaf). */
+int pt_scene_count_stats(PtScene *scene, int enable);
+/* Waits for the device, returns the counters gathered since the last read and
+ * clears them.  Either pointer may be null. */
+int pt_scene_read_stats(PtScene *scene, uint64_t *node_boxes, uint64_t *tri_tests);
+
 /* Seam A, batched: result i equals Scene::castray((ox,oy,oz)[i], (dx,dy,dz)[i])
  * (scene.cpp:18-20 -> object.cpp:265-285,406-429).  tri = global triangle id in
  * file order, -1 and t = +INF on a miss; u, v are HitData::barycentric.x/.y.

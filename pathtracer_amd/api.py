@@ -1,0 +1,273 @@
+"""ctypes binding of the render library's C ABI (include/ptgpu.h).
+
+There is no CPU fallback: if libptgpu.so is missing or no gfx950 device is present,
+loading or the first call fails with an exception.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libptgpu.so")
+
+PT_TRACE_EXACT, PT_TRACE_FAST = 0, 1
+PT_SAMPLE_UNIFORM, PT_SAMPLE_COSINE = 0, 1
+
+
+class PtNode(C.Structure):
+    _fields_ = [("index_or_first", C.c_uint32), ("count", C.c_uint32),
+                ("bmin", C.c_float * 3), ("bmax", C.c_float * 3)]
+
+
+class PtMaterial(C.Structure):
+    _fields_ = [("kd", C.c_float * 3), ("ke", C.c_float * 3)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [("n_meshes", C.c_uint32), ("n_tris", C.c_uint32), ("n_materials", C.c_uint32),
+                ("n_tlas_nodes", C.c_uint32),
+                ("tlas_nodes", C.c_void_p), ("tlas_order", C.c_void_p), ("blas_node_offset", C.c_void_p),
+                ("blas_nodes", C.c_void_p), ("tri_offset", C.c_void_p), ("blas_order", C.c_void_p),
+                ("tri_verts", C.c_void_p), ("mesh_material", C.c_void_p), ("materials", C.c_void_p)]
+
+
+class PtSceneInfo(C.Structure):
+    _fields_ = [("n_meshes", C.c_uint32), ("n_tris", C.c_uint32), ("n_lights", C.c_uint32),
+                ("n_wide_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("device", C.c_uint32),
+                ("device_bytes", C.c_uint64)]
+
+
+class PtCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("euler", C.c_float * 3), ("fov_deg", C.c_float),
+                ("vw", C.c_int32), ("vh", C.c_int32), ("aperture", C.c_float), ("focus", C.c_float)]
+
+
+class PtOptions(C.Structure):
+    _fields_ = [("rr_prob", C.c_float), ("rr_min_depth", C.c_int32), ("max_depth", C.c_int32),
+                ("sampling", C.c_int32), ("bgcolor", C.c_float * 3), ("trace_mode", C.c_int32),
+                ("spp_stride", C.c_uint32), ("batch_spp", C.c_uint32)]
+
+
+class PtCounters(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("node_boxes", C.c_uint64), ("tri_tests", C.c_uint64), ("bounce_passes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+NODE_DTYPE = np.dtype([("index_or_first", "<u4"), ("count", "<u4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3)])
+MAT_DTYPE = np.dtype([("kd", "<f4", 3), ("ke", "<f4", 3)])
+
+# Every symbol include/ptgpu.h declares.
+EXPORTS = [
+    "pt_last_error", "pt_device_count", "pt_options_default", "pt_camera_default", "pt_scene_upload",
+    "pt_scene_free", "pt_scene_info", "pt_scene_count_stats", "pt_scene_read_stats", "pt_trace_closest",
+    "pt_trace_closest_dev", "pt_trace_any", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
+    "pt_philox4x32",
+]
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ptgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libptgpu.so (raises OSError when it has not been built)."""
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_device_count.restype = C.c_int
+        L.pt_options_default.argtypes = [C.POINTER(PtOptions)]
+        L.pt_camera_default.argtypes = [C.POINTER(PtCamera)]
+        L.pt_scene_upload.argtypes = [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.pt_scene_free.argtypes = [C.c_void_p]
+        L.pt_scene_free.restype = None
+        L.pt_scene_info.argtypes = [C.c_void_p, C.POINTER(PtSceneInfo)]
+        L.pt_scene_count_stats.argtypes = [C.c_void_p, C.c_int]
+        L.pt_scene_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.pt_trace_closest.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 10 + [C.c_int]
+        L.pt_trace_closest_dev.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
+        L.pt_trace_any.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.c_int]
+        L.pt_camera_rays.argtypes = [C.POINTER(PtCamera), C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.pt_render.argtypes = [C.c_void_p, C.POINTER(PtCamera), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                C.c_uint64, C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtCounters)]
+        L.pt_render_dev.argtypes = L.pt_render.argtypes + [C.c_void_p]
+        L.pt_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+        L.pt_philox4x32.argtypes = [C.c_void_p] * 3
+        L.pt_philox4x32.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise PtError(rc, lib().pt_last_error().decode())
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    return _check(lib().pt_device_count())
+
+
+def make_camera(origin=(0, 0, 0), euler=(0, 0, 0), fov=65.0, vw=1, vh=1, aperture=0.0, focus=1.0):
+    c = PtCamera()
+    lib().pt_camera_default(C.byref(c))
+    c.origin[:] = origin
+    c.euler[:] = euler
+    c.fov_deg, c.vw, c.vh, c.aperture, c.focus = fov, vw, vh, aperture, focus
+    return c
+
+
+def make_options(**kw):
+    o = PtOptions()
+    lib().pt_options_default(C.byref(o))
+    for k, v in kw.items():
+        if k == "bgcolor":
+            o.bgcolor[:] = v
+        else:
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+    return o
+
+
+def philox(ctr, key):
+    c = np.array(ctr, np.uint32)
+    k = np.array(key, np.uint32)
+    o = np.zeros(4, np.uint32)
+    lib().pt_philox4x32(_p(c), _p(k), _p(o))
+    return o
+
+
+def camera_rays(cam, W, H, device=0):
+    out = np.empty((H, W, 3), np.float32)
+    _check(lib().pt_camera_rays(C.byref(cam), W, H, device, _p(out)))
+    return out
+
+
+def resolve(accum, spp):
+    a = np.ascontiguousarray(accum, np.float32)
+    out = np.empty_like(a)
+    _check(lib().pt_resolve(_p(a), a.size, spp, _p(out)))
+    return out
+
+
+class DeviceScene:
+    """A scene resident in HBM.  `arrays` is a dict with the members of PtSceneDesc as numpy
+    arrays (tlas_nodes, tlas_order, blas_node_offset, blas_nodes, tri_offset, blas_order, tri_verts,
+    mesh_material, materials)."""
+
+    def __init__(self, arrays, device=0):
+        self._h = None
+        a = {
+            "tlas_nodes": np.ascontiguousarray(arrays["tlas_nodes"], NODE_DTYPE),
+            "tlas_order": np.ascontiguousarray(arrays["tlas_order"], np.uint32),
+            "blas_node_offset": np.ascontiguousarray(arrays["blas_node_offset"], np.uint32),
+            "blas_nodes": np.ascontiguousarray(arrays["blas_nodes"], NODE_DTYPE),
+            "tri_offset": np.ascontiguousarray(arrays["tri_offset"], np.uint32),
+            "blas_order": np.ascontiguousarray(arrays["blas_order"], np.uint32),
+            "tri_verts": np.ascontiguousarray(arrays["tri_verts"], np.float32),
+            "mesh_material": np.ascontiguousarray(arrays["mesh_material"], np.uint32),
+            "materials": np.ascontiguousarray(arrays["materials"], MAT_DTYPE),
+        }
+        d = PtSceneDesc()
+        d.n_meshes = len(a["mesh_material"])
+        d.n_tris = len(a["blas_order"])
+        d.n_materials = len(a["materials"])
+        d.n_tlas_nodes = len(a["tlas_nodes"])
+        for k, v in a.items():
+            setattr(d, k, v.ctypes.data)
+        h = C.c_void_p()
+        _check(lib().pt_scene_upload(C.byref(d), device, C.byref(h)))
+        self._h = h
+        self.device = device
+        info = PtSceneInfo()
+        _check(lib().pt_scene_info(self._h, C.byref(info)))
+        self.info = {k: int(getattr(info, k)) for k, _ in info._fields_}
+
+    def close(self):
+        if self._h:
+            lib().pt_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def count_stats(self, enable):
+        _check(lib().pt_scene_count_stats(self._h, int(enable)))
+
+    def read_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().pt_scene_read_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @staticmethod
+    def _cols(o, d):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        if len(o) != len(d):
+            raise ValueError("origins and directions differ in length")
+        return [np.ascontiguousarray(o[:, i]) for i in range(3)] + [np.ascontiguousarray(d[:, i]) for i in range(3)]
+
+    def trace_closest(self, o, d, mode=PT_TRACE_FAST):
+        """Scene::castray for each ray: dict(t, tri, u, v); tri = -1 and t = inf on a miss."""
+        cols = self._cols(o, d)
+        n = len(cols[0])
+        t = np.empty(n, np.float32)
+        tri = np.empty(n, np.int32)
+        u = np.empty(n, np.float32)
+        v = np.empty(n, np.float32)
+        _check(lib().pt_trace_closest(self._h, n, *[_p(c) for c in cols], _p(t), _p(tri), _p(u), _p(v), mode))
+        return dict(t=t, tri=tri, u=u, v=v)
+
+    def trace_any(self, o, d, mode=PT_TRACE_FAST):
+        cols = self._cols(o, d)
+        n = len(cols[0])
+        hit = np.empty(n, np.uint8)
+        _check(lib().pt_trace_any(self._h, n, *[_p(c) for c in cols], _p(hit), mode))
+        return hit.astype(bool)
+
+    def render(self, cam, W, H, spp_count, spp_begin=0, seed=0, opt=None, accum=None):
+        """Adds spp_count samples per pixel to `accum` ([H,W,3] float32 radiance sums, zeros when
+        None).  Returns (accum, PtCounters)."""
+        if accum is None:
+            accum = np.zeros((H, W, 3), np.float32)
+        if accum.dtype != np.float32 or accum.shape != (H, W, 3) or not accum.flags.c_contiguous:
+            raise ValueError("accum must be a contiguous float32 [H,W,3] array")
+        cnt = PtCounters()
+        o = opt if opt is not None else make_options()
+        _check(lib().pt_render(self._h, C.byref(cam), W, H, spp_begin, spp_count, seed, C.byref(o), _p(accum),
+                               C.byref(cnt)))
+        return accum, cnt
+
+    def render_dev(self, cam, W, H, spp_count, accum_ptr, spp_begin=0, seed=0, opt=None, stream=None):
+        """Same with `accum_ptr` an integer device address of W*H*3 floats on this scene's device."""
+        cnt = PtCounters()
+        o = opt if opt is not None else make_options()
+        _check(lib().pt_render_dev(self._h, C.byref(cam), W, H, spp_begin, spp_count, seed, C.byref(o),
+                                   C.c_void_p(accum_ptr), C.byref(cnt), C.c_void_p(stream or 0)))
+        return cnt
+
+    def trace_closest_dev(self, n, ptrs, out_ptrs, mode=PT_TRACE_FAST, stream=None):
+        """ptrs = (ox,oy,oz,dx,dy,dz), out_ptrs = (t,tri,u,v): integer device addresses."""
+        _check(lib().pt_trace_closest_dev(self._h, n, *[C.c_void_p(p) for p in ptrs],
+                                          *[C.c_void_p(p or 0) for p in out_ptrs], mode, C.c_void_p(stream or 0)))

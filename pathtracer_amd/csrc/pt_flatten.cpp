@@ -1,0 +1,347 @@
+// pt_flatten.cpp — turns the reference-shaped two-level BVH of a PtSceneDesc into
+// the single device tree the gfx950 kernels walk.
+//
+// What the reference's recursive BVH::intersect (object.cpp:265-285) returns is
+// fully described by (a) the set of leaves it reaches — a leaf is reached when
+// every INTERNAL ancestor's own box test passes; leaves themselves and whole
+// meshes inside a top-level leaf are never box-tested — and (b) a tie rule among
+// equal t: inside a leaf the leftmost minimum wins (std::ranges::min), between
+// siblings the right child wins (`lhit.t < rhit.t ? lhit : rhit`).  Rule (b) is a
+// total order over triangle positions, so triangles are stored in that order and
+// "larger slot wins a tie" reproduces it for any visiting order.  Rule (a) is kept
+// by tagging each child slot with its kind (pt_layout.h).
+#include "pt_flatten.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+
+namespace ptl {
+namespace {
+
+struct Entry {
+  float lo[3], hi[3];
+  uint32_t ref;
+  uint32_t kind;
+  uint32_t depth;
+};
+
+const uint32_t kTopNodes = 2047;   // nodes numbered breadth-first from the root
+const uint32_t kMaxRecursion = 4096;
+
+struct Flattener {
+  const PtSceneDesc &d;
+  FlatScene &out;
+  std::string &err;
+  std::vector<WideNode> nodes;       // creation order; renumbered at the end
+  std::vector<uint8_t> tri_seen;     // per global triangle
+  std::vector<uint8_t> mesh_seen;
+  std::vector<uint8_t> tlas_seen;
+  std::vector<uint8_t> blas_seen;    // per global blas node
+  uint32_t next_slot = 0;
+  bool failed = false;
+
+  Flattener(const PtSceneDesc &dd, FlatScene &o, std::string &e) : d(dd), out(o), err(e) {}
+
+  Entry fail(const char *msg) {
+    if (!failed) err = msg;
+    failed = true;
+    Entry e;
+    memset(&e, 0, sizeof(e));
+    e.kind = KIND_EMPTY;
+    return e;
+  }
+
+  static void set_box(Entry &e, const PtNode &n) {
+    for (int k = 0; k < 3; ++k) {
+      e.lo[k] = n.bmin[k];
+      e.hi[k] = n.bmax[k];
+    }
+  }
+
+  uint32_t make_node(const Entry &a, const Entry &b) {
+    WideNode w;
+    for (int k = 0; k < 3; ++k) {
+      w.lo0[k] = a.lo[k]; w.hi0[k] = a.hi[k];
+      w.lo1[k] = b.lo[k]; w.hi1[k] = b.hi[k];
+    }
+    w.ref0 = a.ref; w.ref1 = b.ref;
+    w.kind0 = a.kind; w.kind1 = b.kind;
+    nodes.push_back(w);
+    return (uint32_t)nodes.size() - 1;
+  }
+
+  static Entry empty_entry() {
+    Entry e;
+    for (int k = 0; k < 3; ++k) {
+      e.lo[k] = INFINITY;
+      e.hi[k] = -INFINITY;
+    }
+    e.ref = 0;
+    e.kind = KIND_EMPTY;
+    e.depth = 0;
+    return e;
+  }
+
+  // Balanced grouping nodes over es[lo, hi).
+  Entry group(const std::vector<Entry> &es, size_t lo, size_t hi) {
+    if (hi - lo == 1) return es[lo];
+    size_t mid = lo + (hi - lo) / 2;
+    Entry a = group(es, lo, mid), b = group(es, mid, hi);
+    Entry g;
+    for (int k = 0; k < 3; ++k) {
+      g.lo[k] = std::min(a.lo[k], b.lo[k]);
+      g.hi[k] = std::max(a.hi[k], b.hi[k]);
+    }
+    g.ref = make_node(a, b);
+    g.kind = KIND_GROUP;
+    g.depth = 1 + std::max(a.depth, b.depth);
+    return g;
+  }
+
+  void put_triangle(uint32_t mesh, uint32_t local) {
+    const uint32_t gid = d.tri_offset[mesh] + local;
+    const float *p = d.tri_verts + (size_t)gid * 9;
+    TriRec r;
+    for (int k = 0; k < 3; ++k) {
+      r.v0[k] = p[k];
+      r.e1[k] = p[3 + k] - p[k];
+      r.e2[k] = p[6 + k] - p[k];
+    }
+    r.tri_id = gid;
+    r.mat_id = d.mesh_material[mesh];
+    r.mesh_id = mesh;
+    out.tris.push_back(r);
+    ++next_slot;
+  }
+
+  Entry mesh_node(uint32_t mesh, uint32_t local, uint32_t level) {
+    const uint32_t nb = d.blas_node_offset[mesh], ne = d.blas_node_offset[mesh + 1];
+    const uint32_t ntri = d.tri_offset[mesh + 1] - d.tri_offset[mesh];
+    if (level > kMaxRecursion) return fail("mesh tree deeper than 4096 levels");
+    if (local >= ne - nb) return fail("mesh node index out of range");
+    if (blas_seen[nb + local]) return fail("mesh node referenced twice");
+    blas_seen[nb + local] = 1;
+    const PtNode &n = d.blas_nodes[nb + local];
+    Entry e;
+    set_box(e, n);
+    if (n.count > 0) {
+      if ((uint64_t)n.index_or_first + n.count > ntri) return fail("leaf range outside its mesh");
+      const uint32_t first_slot = next_slot;
+      for (uint32_t pos = n.count; pos-- > 0;) {  // leftmost position gets the largest slot
+        const uint32_t local_tri = d.blas_order[d.tri_offset[mesh] + n.index_or_first + pos];
+        if (local_tri >= ntri) return fail("blas_order entry out of range");
+        if (tri_seen[d.tri_offset[mesh] + local_tri]) return fail("triangle referenced twice");
+        tri_seen[d.tri_offset[mesh] + local_tri] = 1;
+        put_triangle(mesh, local_tri);
+      }
+      if (next_slot > MAX_TRI_SLOTS) return fail("more than 2^28 triangles");
+      std::vector<Entry> chunks;
+      for (uint32_t s = first_slot; s < next_slot; s += 8) {
+        Entry c = e;
+        const uint32_t cnt = std::min<uint32_t>(8, next_slot - s);
+        c.ref = REF_LEAF | ((cnt - 1) << 28) | s;
+        c.kind = KIND_LEAF;
+        c.depth = 0;
+        chunks.push_back(c);
+      }
+      return group(chunks, 0, chunks.size());
+    }
+    Entry l = mesh_node(mesh, n.index_or_first, level + 1);
+    Entry r = mesh_node(mesh, n.index_or_first + 1, level + 1);
+    if (failed) return e;
+    e.ref = make_node(l, r);
+    e.kind = KIND_INTERNAL;
+    e.depth = 1 + std::max(l.depth, r.depth);
+    return e;
+  }
+
+  Entry tlas_node(uint32_t i, uint32_t level) {
+    if (level > kMaxRecursion) return fail("top-level tree deeper than 4096 levels");
+    if (i >= d.n_tlas_nodes) return fail("top-level node index out of range");
+    if (tlas_seen[i]) return fail("top-level node referenced twice");
+    tlas_seen[i] = 1;
+    const PtNode &n = d.tlas_nodes[i];
+    Entry e;
+    set_box(e, n);
+    if (n.count > 0) {
+      if ((uint64_t)n.index_or_first + n.count > d.n_meshes) return fail("top-level leaf range out of range");
+      std::vector<Entry> es;
+      for (uint32_t pos = n.count; pos-- > 0;) {
+        const uint32_t mesh = d.tlas_order[n.index_or_first + pos];
+        if (mesh >= d.n_meshes) return fail("tlas_order entry out of range");
+        if (mesh_seen[mesh]) return fail("mesh referenced twice");
+        mesh_seen[mesh] = 1;
+        if (d.blas_node_offset[mesh + 1] <= d.blas_node_offset[mesh]) return fail("mesh without nodes");
+        es.push_back(mesh_node(mesh, 0, level + 1));
+        if (failed) return e;
+      }
+      return group(es, 0, es.size());
+    }
+    Entry l = tlas_node(n.index_or_first, level + 1);
+    Entry r = tlas_node(n.index_or_first + 1, level + 1);
+    if (failed) return e;
+    e.ref = make_node(l, r);
+    e.kind = KIND_INTERNAL;
+    e.depth = 1 + std::max(l.depth, r.depth);
+    return e;
+  }
+
+  // Root first, the top of the tree breadth-first, the rest depth-first.
+  void renumber(uint32_t root) {
+    const uint32_t n = (uint32_t)nodes.size();
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    std::deque<uint32_t> q;
+    q.push_back(root);
+    auto kids = [&](uint32_t i, uint32_t k[2]) {
+      int c = 0;
+      const WideNode &w = nodes[i];
+      if (w.kind0 != KIND_EMPTY && !(w.ref0 & REF_LEAF)) k[c++] = w.ref0;
+      if (w.kind1 != KIND_EMPTY && !(w.ref1 & REF_LEAF)) k[c++] = w.ref1;
+      return c;
+    };
+    while (!q.empty() && order.size() < kTopNodes) {
+      uint32_t i = q.front();
+      q.pop_front();
+      order.push_back(i);
+      uint32_t k[2];
+      int c = kids(i, k);
+      for (int j = 0; j < c; ++j) q.push_back(k[j]);
+    }
+    std::vector<uint32_t> st;
+    for (uint32_t start : q) {
+      st.push_back(start);
+      while (!st.empty()) {
+        uint32_t i = st.back();
+        st.pop_back();
+        order.push_back(i);
+        uint32_t k[2];
+        int c = kids(i, k);
+        for (int j = c - 1; j >= 0; --j) st.push_back(k[j]);
+      }
+    }
+    std::vector<uint32_t> newidx(n, 0);
+    for (uint32_t j = 0; j < order.size(); ++j) newidx[order[j]] = j;
+    out.nodes.resize(order.size());
+    for (uint32_t j = 0; j < order.size(); ++j) {
+      WideNode w = nodes[order[j]];
+      if (w.kind0 != KIND_EMPTY && !(w.ref0 & REF_LEAF)) w.ref0 = newidx[w.ref0];
+      if (w.kind1 != KIND_EMPTY && !(w.ref1 & REF_LEAF)) w.ref1 = newidx[w.ref1];
+      out.nodes[j] = w;
+    }
+  }
+
+  // Scene::lights() in top-level object order with the reference's areas.
+  void build_lights() {
+    for (uint32_t pos = 0; pos < d.n_meshes; ++pos) {
+      const uint32_t mesh = d.tlas_order[pos];
+      const PtMaterial &m = d.materials[d.mesh_material[mesh]];
+      if (m.ke[0] == 0 && m.ke[1] == 0 && m.ke[2] == 0) continue;  // emission != vec(0,0,0), scene.cpp:25
+      LightRec L;
+      L.first = (uint32_t)out.light_tris.size();
+      L.count = d.tri_offset[mesh + 1] - d.tri_offset[mesh];
+      double area = 0;
+      for (uint32_t t = d.tri_offset[mesh]; t < d.tri_offset[mesh + 1]; ++t) {
+        const float *p = d.tri_verts + (size_t)t * 9;
+        const float *a = p, *b = p + 3, *c = p + 6;
+        // Triangle::area, object.cpp:395-404: float shoelace on x,y only, widened afterwards
+        float s = std::fabs(a[0] * (b[1] - c[1]) + b[0] * (c[1] - a[1]) + c[0] * (a[1] - b[1])) / 2;
+        area += (double)s;
+        LightTri lt;
+        for (int k = 0; k < 3; ++k) {
+          lt.u[k] = b[k] - a[k];
+          lt.v[k] = c[k] - a[k];
+        }
+        lt.n[0] = lt.u[1] * lt.v[2] - lt.u[2] * lt.v[1];
+        lt.n[1] = lt.u[2] * lt.v[0] - lt.u[0] * lt.v[2];
+        lt.n[2] = lt.u[0] * lt.v[1] - lt.u[1] * lt.v[0];
+        lt.pad = 0;
+        lt.accum = area;
+        out.light_tris.push_back(lt);
+      }
+      L.area_f = (float)area;
+      L.inv_area_f = (float)(1 / area);
+      for (int k = 0; k < 3; ++k) L.ke[k] = m.ke[k];
+      L.mesh_id = mesh;
+      out.lights.push_back(L);
+    }
+  }
+
+  int run() {
+    if (!d.tlas_nodes || !d.tlas_order || !d.blas_node_offset || !d.blas_nodes || !d.tri_offset ||
+        !d.blas_order || !d.tri_verts || !d.mesh_material || !d.materials) {
+      err = "null array in PtSceneDesc";
+      return PT_ERR_INVALID;
+    }
+    if (d.n_meshes == 0 || d.n_tris == 0 || d.n_tlas_nodes == 0 || d.n_materials == 0) {
+      err = "empty scene";
+      return PT_ERR_INVALID;
+    }
+    if (d.tri_offset[0] != 0 || d.tri_offset[d.n_meshes] != d.n_tris || d.blas_node_offset[0] != 0) {
+      err = "offset arrays do not start at 0 / end at the totals";
+      return PT_ERR_INVALID;
+    }
+    for (uint32_t m = 0; m < d.n_meshes; ++m) {
+      if (d.tri_offset[m + 1] < d.tri_offset[m] || d.blas_node_offset[m + 1] < d.blas_node_offset[m]) {
+        err = "offset arrays are not monotone";
+        return PT_ERR_INVALID;
+      }
+      if (d.tri_offset[m + 1] == d.tri_offset[m]) {
+        err = "mesh without triangles";
+        return PT_ERR_INVALID;
+      }
+      if (d.mesh_material[m] >= d.n_materials) {
+        err = "mesh_material out of range";
+        return PT_ERR_INVALID;
+      }
+    }
+    if (d.n_tris > MAX_TRI_SLOTS) {
+      err = "more than 2^28 triangles";
+      return PT_ERR_UNSUPPORTED;
+    }
+    tri_seen.assign(d.n_tris, 0);
+    mesh_seen.assign(d.n_meshes, 0);
+    tlas_seen.assign(d.n_tlas_nodes, 0);
+    blas_seen.assign(d.blas_node_offset[d.n_meshes], 0);
+    out.tris.reserve(d.n_tris);
+    Entry root = tlas_node(0, 0);
+    if (failed) return PT_ERR_INVALID;
+    if (next_slot != d.n_tris) {
+      err = "tree does not reach every triangle";
+      return PT_ERR_INVALID;
+    }
+    for (uint32_t m = 0; m < d.n_meshes; ++m)
+      if (!mesh_seen[m]) {
+        err = "tree does not reach every mesh";
+        return PT_ERR_INVALID;
+      }
+    Entry none = empty_entry();
+    uint32_t super = make_node(root, none);
+    out.max_depth = root.depth + 1;
+    renumber(super);
+    out.mats.resize(d.n_materials);
+    for (uint32_t i = 0; i < d.n_materials; ++i) {
+      MatRec &r = out.mats[i];
+      for (int k = 0; k < 3; ++k) {
+        r.kd[k] = d.materials[i].kd[k];
+        r.ke[k] = d.materials[i].ke[k];
+      }
+      r.pad0 = r.pad1 = 0;
+    }
+    build_lights();
+    out.n_meshes = d.n_meshes;
+    return PT_OK;
+  }
+};
+
+}  // namespace
+
+int flatten_scene(const PtSceneDesc &d, FlatScene &out, std::string &err) {
+  out = FlatScene();
+  Flattener f(d, out, err);
+  return f.run();
+}
+
+}  // namespace ptl

@@ -1,0 +1,27 @@
+// pt_flatten.h — host-side conversion of a PtSceneDesc into the device layout.
+#ifndef PT_FLATTEN_H
+#define PT_FLATTEN_H
+
+#include <string>
+#include <vector>
+
+#include "../../include/ptgpu.h"
+#include "pt_layout.h"
+
+namespace ptl {
+
+struct FlatScene {
+  std::vector<WideNode> nodes;       // node 0 is the super-root
+  std::vector<TriRec> tris;          // in tie-rank order
+  std::vector<MatRec> mats;
+  std::vector<LightRec> lights;
+  std::vector<LightTri> light_tris;
+  uint32_t max_depth = 0;            // stack entries the deepest descent needs
+  uint32_t n_meshes = 0;
+};
+
+// Returns PT_OK or a negative PtStatus with `err` filled in.
+int flatten_scene(const PtSceneDesc &d, FlatScene &out, std::string &err);
+
+}  // namespace ptl
+#endif

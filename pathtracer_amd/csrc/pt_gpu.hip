@@ -1,0 +1,856 @@
+// pt_gpu.hip — gfx950 kernels of the render hot path and the C ABI in front of them
+// (include/ptgpu.h).  Wavefront organisation: every stage is its own kernel over a
+// structure-of-arrays queue of live paths; one lane carries one ray.
+//
+//   k_raygen        Camera::point_towards (camera.cpp:161-169) [+ thin lens]  -> path queue
+//   k_trace_queue   Scene::castray (scene.cpp:18-20) for every queued ray     -> hit buffer
+//   k_shade         the body of Camera::pathtrace (camera.cpp:63-159) for one path vertex:
+//                   normal, the light loop with its visibility rays, Russian roulette, the
+//                   next direction, throughput update, and compaction of the survivors
+//   k_resolve       adds the finished samples of a batch to the caller's accumulator
+//   k_trace_api / k_any_api   Seam A for callers that bring their own rays
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pt_device.h"
+#include "pt_flatten.h"
+
+using namespace ptd;
+
+// ===================================================================== device side
+
+static const int kBlock = 256;
+
+struct QueueDev {  // one live path per index, arrays `cap` long
+  float *ox, *oy, *oz, *dx, *dy, *dz;  // ray
+  float *tx, *ty, *tz;                 // throughput
+  float *lx, *ly, *lz;                 // radiance gathered so far
+  uint32_t *id;                        // sample_in_batch * P + pixel
+};
+
+struct FrameDev {
+  int W, H;
+  uint32_t P;            // W*H
+  float origin[3];
+  double rot[9];         // rotate() coefficients, math.cpp:130-140, row-major
+  float vw, neg_vh;      // (float)vw, (float)(-vh)
+  float pin_z;           // third component of point_towards before the rotation
+  float aperture, focus;
+  uint64_t seed;
+  uint32_t sample0;      // global index of the batch's first sample
+  uint32_t stride;       // distance between consecutive samples' global indices
+  float rr_prob;
+  int rr_min_depth, max_depth, sampling;
+  float bg[3];
+  float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
+  float pi_f;            // (float)M_PI, camera.cpp:122
+  uint32_t dims_per_vertex;
+};
+
+__device__ __forceinline__ V3 rotate9(const double *c, V3 p) {
+  const double px = p.x, py = p.y, pz = p.z;
+  V3 r;
+  r.x = (float)((c[0] * px) + (c[1] * py) + (c[2] * pz));
+  r.y = (float)((c[3] * px) + (c[4] * py) + (c[5] * pz));
+  r.z = (float)((c[6] * px) + (c[7] * py) + (c[8] * pz));
+  return r;
+}
+
+__device__ __forceinline__ void camera_ray(const FrameDev &F, int px, int py, PathRng &rng, V3 &o, V3 &d) {
+  // camera.cpp:162-167: float arithmetic on x and y, z prepared in double by the host
+  const float x = ((float)px - (float)F.W / 2) * F.vw / (float)F.W;
+  const float y = ((float)py - (float)F.H / 2) * F.neg_vh / (float)F.H;
+  const V3 dc = mk(x, y, F.pin_z);
+  if (F.aperture > 0.0f) {  // thin lens: not in the reference
+    const float u1 = rng.real(0.0f, 1.0f, 0), u2 = rng.real(0.0f, 1.0f, 1);
+    const float r = F.aperture * sqrtf(u1);
+    const double ph = 2 * M_PI * (double)u2;
+    const V3 lens = mk((float)(cos(ph) * (double)r), (float)(sin(ph) * (double)r), 0.0f);
+    const float s = F.focus / dc.z;
+    const V3 pf = scale(dc, s);
+    const float inv_s = dc.z / F.focus;
+    const V3 dl = scale(sub(pf, lens), inv_s);
+    o = add(mk(F.origin[0], F.origin[1], F.origin[2]), rotate9(F.rot, lens));
+    d = rotate9(F.rot, dl);
+  } else {
+    o = mk(F.origin[0], F.origin[1], F.origin[2]);
+    d = rotate9(F.rot, dc);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_raygen(FrameDev F, uint32_t n, QueueDev q) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = i / F.P, p = i - s * F.P;
+  const int py = (int)(p / (uint32_t)F.W), px = (int)(p - (uint32_t)py * (uint32_t)F.W);
+  PathRng rng;
+  rng.init(F.seed, p, F.sample0 + s * F.stride);
+  V3 o, d;
+  camera_ray(F, px, py, rng, o, d);
+  q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
+  q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
+  q.tx[i] = 1.0f; q.ty[i] = 1.0f; q.tz[i] = 1.0f;
+  q.lx[i] = 0.0f; q.ly[i] = 0.0f; q.lz[i] = 0.0f;
+  q.id[i] = i;
+}
+
+// Camera::point_towards for every pixel, for callers that only want the directions.
+__global__ __launch_bounds__(kBlock) void k_camera_dirs(FrameDev F, float *dir) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= F.P) return;
+  const int py = (int)(p / (uint32_t)F.W), px = (int)(p - (uint32_t)py * (uint32_t)F.W);
+  PathRng rng;
+  rng.init(F.seed, p, 0);
+  FrameDev G = F;
+  G.aperture = 0.0f;
+  V3 o, d;
+  camera_ray(G, px, py, rng, o, d);
+  dir[3 * (size_t)p + 0] = d.x;
+  dir[3 * (size_t)p + 1] = d.y;
+  dir[3 * (size_t)p + 2] = d.z;
+}
+
+__device__ __forceinline__ void wave_add64(unsigned long long *dst, uint32_t v) {
+  uint32_t s = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, (unsigned long long)s);
+}
+
+template <int MODE, int STACK, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_queue(SceneDev S, uint32_t n, QueueDev q, float *hit_t,
+                                                        uint32_t *hit_slot, unsigned long long *stats) {
+  __shared__ uint32_t stk[STACK * kBlock];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t nb = 0, nt = 0;
+  if (i < n) {
+    const V3 o = mk(q.ox[i], q.oy[i], q.oz[i]);
+    const V3 d = mk(q.dx[i], q.dy[i], q.dz[i]);
+    HitRec h;
+    walk<MODE, false, COUNT>(S, o, d, stk + threadIdx.x, kBlock, h, nb, nt);
+    hit_t[i] = h.t;
+    hit_slot[i] = h.slot;
+  }
+  if (COUNT) {
+    wave_add64(stats + 0, nb);
+    wave_add64(stats + 1, nt);
+  }
+}
+
+template <int MODE, int STACK, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_api(SceneDev S, size_t n, const float *ox, const float *oy,
+                                                      const float *oz, const float *dx, const float *dy,
+                                                      const float *dz, float *t, int32_t *tri, float *u, float *v,
+                                                      unsigned long long *stats) {
+  __shared__ uint32_t stk[STACK * kBlock];
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t nb = 0, nt = 0;
+  if (i < n) {
+    const V3 o = mk(ox[i], oy[i], oz[i]);
+    const V3 d = mk(dx[i], dy[i], dz[i]);
+    HitRec h;
+    const bool hit = walk<MODE, false, COUNT>(S, o, d, stk + threadIdx.x, kBlock, h, nb, nt);
+    t[i] = h.t;
+    tri[i] = hit ? (int32_t)S.tris[h.slot].tri_id : -1;
+    if (u) u[i] = h.u;
+    if (v) v[i] = h.v;
+  }
+  if (COUNT) {
+    wave_add64(stats + 0, nb);
+    wave_add64(stats + 1, nt);
+  }
+}
+
+template <int MODE, int STACK>
+__global__ __launch_bounds__(kBlock) void k_any_api(SceneDev S, size_t n, const float *ox, const float *oy,
+                                                    const float *oz, const float *dx, const float *dy,
+                                                    const float *dz, uint8_t *hit) {
+  __shared__ uint32_t stk[STACK * kBlock];
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  HitRec h;
+  uint32_t nb = 0, nt = 0;
+  hit[i] = walk<MODE, true, false>(S, mk(ox[i], oy[i], oz[i]), mk(dx[i], dy[i], dz[i]), stk + threadIdx.x, kBlock, h,
+                                   nb, nt)
+               ? 1
+               : 0;
+}
+
+// random_direction, camera.cpp:77-90
+__device__ __forceinline__ V3 uniform_dir(V3 n, float x, float y) {
+  const float phi = 1.0f - 2.0f * x;
+  const float theta = (float)fmax(0.0, (double)(1.0f - phi * phi));
+  const float st = sqrtf(theta);
+  const double ang = 2 * M_PI * (double)y;
+  V3 v = mk((float)(cos(ang) * (double)st), (float)(sin(ang) * (double)st), phi);
+  v = normalize(v);
+  return dot(v, n) < 0.0f ? neg(v) : v;
+}
+// cosine-weighted direction about n: not in the reference
+__device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
+  const float r = sqrtf(x);
+  const float lz = sqrtf(fmaxf(0.0f, 1.0f - x));
+  const double ang = 2 * M_PI * (double)y;
+  const float lx = (float)(cos(ang) * (double)r), ly = (float)(sin(ang) * (double)r);
+  const float s = copysignf(1.0f, n.z);
+  const float a = -1.0f / (s + n.z);
+  const float b = n.x * n.y * a;
+  const V3 t1 = mk(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
+  const V3 t2 = mk(b, s + n.y * n.y * a, -n.y);
+  return add(add(scale(t1, lx), scale(t2, ly)), scale(n, lz));
+}
+
+// One path vertex.  cnt[0] = survivors written to `out`, cnt[1] = paths that hit something.
+template <int MODE, int STACK, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev S, FrameDev F, int depth, uint32_t n, QueueDev in,
+                                                  const float *hit_t, const uint32_t *hit_slot, QueueDev out,
+                                                  uint32_t *cnt, float *Lr, float *Lg, float *Lb,
+                                                  unsigned long long *stats) {
+  __shared__ uint32_t stk[STACK * kBlock];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const bool active = i < n;
+  bool alive = false, did_hit = false;
+  V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
+  uint32_t id = 0;
+  uint32_t nb = 0, nt = 0;
+  if (active) {
+    id = in.id[i];
+    T = mk(in.tx[i], in.ty[i], in.tz[i]);
+    L = mk(in.lx[i], in.ly[i], in.lz[i]);
+    const float t = hit_t[i];
+    if (t == __builtin_inff()) {  // camera.cpp:65-66
+      L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
+    } else {
+      did_hit = true;
+      o = mk(in.ox[i], in.oy[i], in.oz[i]);
+      d = mk(in.dx[i], in.dy[i], in.dz[i]);
+      const uint32_t slot = hit_slot[i];
+      const float4 *tp = reinterpret_cast<const float4 *>(S.tris + slot);
+      const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+      const V3 e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tc.x);
+      const uint32_t mat_id = __float_as_uint(tc.z);
+      const V3 x = add(o, scale(d, t));                    // camera.cpp:68
+      V3 nrm = normalize(cross(e1, e2));                   // camera.cpp:69
+      if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);   // camera.cpp:72-73
+      const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
+      const float4 m0 = mp[0], m1 = mp[1];
+      const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
+
+      PathRng rng;
+      rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
+      const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
+
+      // direct light: every light at every vertex, camera.cpp:96-115
+      V3 local = mk(0, 0, 0);
+      for (uint32_t l = 0; l < S.n_lights; ++l) {
+        const float4 *lp = reinterpret_cast<const float4 *>(S.lights + l);
+        const float4 l0 = lp[0], l1 = lp[1];
+        const uint32_t first = __float_as_uint(l0.x), count = __float_as_uint(l0.y);
+        const float area_f = l0.z, inv_area_f = l0.w;
+        const V3 lke = mk(l1.x, l1.y, l1.z);
+        // Polygon::sample, object.cpp:513-523: first triangle whose running area reaches r
+        const double r = (double)rng.real(0.0f, area_f, base + 3u * l);
+        uint32_t lo = 0, hi = count - 1;  // past the end the reference is undefined; take the last
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (r <= S.light_tris[first + mid].accum) hi = mid; else lo = mid + 1;
+        }
+        const float4 *qp = reinterpret_cast<const float4 *>(S.light_tris + first + lo);
+        const float4 g0 = qp[0], g1 = qp[1], g2 = qp[2];
+        const V3 lu = mk(g0.x, g0.y, g0.z), lv = mk(g0.w, g1.x, g1.y), ln = mk(g1.z, g1.w, g2.x);
+        // Triangle::sample, object.cpp:432-442 (the point is relative to v0; v0 is not added)
+        const double s = (double)rng.real(0.0f, 1.0f, base + 3u * l + 1u);
+        const double tt = (double)rng.real(0.0f, 1.0f, base + 3u * l + 2u);
+        V3 point;
+        if (s + tt <= 1.0) point = add(scale(lu, (float)s), scale(lv, (float)tt));
+        else point = add(scale(lu, (float)(1.0 - s)), scale(lv, (float)(1.0 - tt)));
+        const V3 to = normalize(sub(point, x));
+        HitRec sh;
+        // camera.cpp:101-102: the light is skipped only when this ray hits nothing
+        if (!walk<MODE, true, COUNT>(S, x, to, stk + threadIdx.x, kBlock, sh, nb, nt)) continue;
+        float c = dot(to, nrm);
+        if (c < 0.0f) c = 0.0f;
+        float y = dot(to, ln);
+        if (y < 0.0f) y = 0.0f;
+        const double nn = (double)norm(to);
+        y = (float)((double)y / (nn * nn));  // std::pow(norm, 2) in double, camera.cpp:111
+        local = add(local, scale(scale(scale(lke, c), y), inv_area_f));
+      }
+
+      // Russian roulette, camera.cpp:118-119; the draw happens only when depth > rr_min_depth
+      bool cont = depth <= F.rr_min_depth ||
+                  (double)rng.real(0.0f, 1.0f, base + 3u * S.n_lights) < (double)F.rr_prob;
+      if (F.max_depth > 0 && depth >= F.max_depth) cont = false;
+      if (cont) local = add(local, ke);  // camera.cpp:154
+      L = add(L, mul(T, local));
+      if (cont) {
+        const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
+        const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
+        V3 w;
+        if (F.sampling == PT_SAMPLE_COSINE) {
+          w = cosine_dir(nrm, rx, ry);
+          T = divs(mul(T, kd), F.rr_prob);
+        } else {
+          w = uniform_dir(nrm, rx, ry);
+          const V3 brdf = divs(kd, F.pi_f);                                   // camera.cpp:122
+          T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+        }
+        o = x;  // no offset along the normal, camera.cpp:155
+        d = w;
+        alive = true;
+      }
+    }
+  }
+  // compaction of the survivors: wave ballot + prefix count, one atomic per wave
+  const unsigned long long m = __ballot(alive);
+  const unsigned long long mh = __ballot(did_hit);
+  const int lane = threadIdx.x & 63;
+  uint32_t base_out = 0;
+  if (lane == 0) {
+    if (m) base_out = atomicAdd(&cnt[0], (uint32_t)__popcll(m));
+    if (mh) atomicAdd(&cnt[1], (uint32_t)__popcll(mh));
+  }
+  base_out = __shfl(base_out, 0);
+  if (alive) {
+    const uint32_t j = base_out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    out.ox[j] = o.x; out.oy[j] = o.y; out.oz[j] = o.z;
+    out.dx[j] = d.x; out.dy[j] = d.y; out.dz[j] = d.z;
+    out.tx[j] = T.x; out.ty[j] = T.y; out.tz[j] = T.z;
+    out.lx[j] = L.x; out.ly[j] = L.y; out.lz[j] = L.z;
+    out.id[j] = id;
+  } else if (active) {
+    Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
+  }
+  if (COUNT) {
+    wave_add64(stats + 0, nb);
+    wave_add64(stats + 1, nt);
+  }
+}
+
+// accum[p] += sum over the batch's samples, in sample order (so the float sum does not
+// depend on how paths were scheduled).
+__global__ __launch_bounds__(kBlock) void k_resolve(uint32_t P, uint32_t S, const float *Lr, const float *Lg,
+                                                    const float *Lb, float *accum) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  float r = accum[3 * (size_t)p + 0], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
+  for (uint32_t s = 0; s < S; ++s) {
+    const size_t k = (size_t)s * P + p;
+    r += Lr[k]; g += Lg[k]; b += Lb[k];
+  }
+  accum[3 * (size_t)p + 0] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
+}
+
+// ===================================================================== host side
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(e_ == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_DEVICE,                   \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+  } while (0)
+
+struct Workspace {
+  size_t cap = 0;
+  float *block = nullptr;  // 2 queues x 13 arrays + hit_t + hit_slot + 3 radiance arrays
+  QueueDev q[2];
+  float *hit_t = nullptr;
+  uint32_t *hit_slot = nullptr;
+  float *Lr = nullptr, *Lg = nullptr, *Lb = nullptr;
+};
+
+struct PtScene {
+  int device = 0;
+  SceneDev dev{};
+  ptl::WideNode *d_nodes = nullptr;
+  ptl::TriRec *d_tris = nullptr;
+  ptl::MatRec *d_mats = nullptr;
+  ptl::LightRec *d_lights = nullptr;
+  ptl::LightTri *d_ltris = nullptr;
+  uint32_t max_depth = 0, n_meshes = 0;
+  uint64_t bytes = 0;
+  Workspace ws;
+  uint32_t *d_cnt = nullptr;               // 2 words per pass
+  unsigned long long *d_stats = nullptr;   // node boxes, triangle tests
+  uint32_t *h_cnt = nullptr;               // pinned
+  unsigned long long *h_stats = nullptr;   // pinned
+  bool count_stats = false;
+};
+
+static int stack_class(uint32_t depth) {
+  if (depth <= 16) return 16;
+  if (depth <= 32) return 32;
+  if (depth <= 64) return 64;
+  if (depth <= 128) return 128;
+  return 0;
+}
+
+static void free_workspace(Workspace &w) {
+  if (w.block) (void)hipFree(w.block);
+  w = Workspace();
+}
+
+static int ensure_workspace(PtScene *s, size_t cap) {
+  Workspace &w = s->ws;
+  if (w.cap >= cap) return PT_OK;
+  free_workspace(w);
+  const size_t arrays = 2 * 13 + 2 + 3;
+  const size_t stride = (cap + 63) & ~(size_t)63;
+  HIP_TRY(hipMalloc(&w.block, arrays * stride * sizeof(float)));
+  float *p = w.block;
+  auto take = [&]() { float *r = p; p += stride; return r; };
+  for (int k = 0; k < 2; ++k) {
+    QueueDev &q = w.q[k];
+    q.ox = take(); q.oy = take(); q.oz = take(); q.dx = take(); q.dy = take(); q.dz = take();
+    q.tx = take(); q.ty = take(); q.tz = take(); q.lx = take(); q.ly = take(); q.lz = take();
+    q.id = reinterpret_cast<uint32_t *>(take());
+  }
+  w.hit_t = take();
+  w.hit_slot = reinterpret_cast<uint32_t *>(take());
+  w.Lr = take(); w.Lg = take(); w.Lb = take();
+  w.cap = cap;
+  return PT_OK;
+}
+
+template <int MODE, bool COUNT>
+static int launch_trace_queue(PtScene *s, uint32_t n, const QueueDev &q, hipStream_t st) {
+  const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+  switch (stack_class(s->max_depth)) {
+    case 16: hipLaunchKernelGGL((k_trace_queue<MODE, 16, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
+    case 32: hipLaunchKernelGGL((k_trace_queue<MODE, 32, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
+    case 64: hipLaunchKernelGGL((k_trace_queue<MODE, 64, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
+    case 128: hipLaunchKernelGGL((k_trace_queue<MODE, 128, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
+    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  }
+  HIP_TRY(hipGetLastError());
+  return PT_OK;
+}
+
+template <int MODE, bool COUNT>
+static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, const QueueDev &in,
+                        const QueueDev &out, uint32_t *cnt, hipStream_t st) {
+  const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+  const Workspace &w = s->ws;
+  switch (stack_class(s->max_depth)) {
+    case 16: hipLaunchKernelGGL((k_shade<MODE, 16, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
+    case 32: hipLaunchKernelGGL((k_shade<MODE, 32, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
+    case 64: hipLaunchKernelGGL((k_shade<MODE, 64, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
+    case 128: hipLaunchKernelGGL((k_shade<MODE, 128, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
+    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  }
+  HIP_TRY(hipGetLastError());
+  return PT_OK;
+}
+
+template <int MODE, bool COUNT>
+static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz,
+                            const float *dx, const float *dy, const float *dz, float *t, int32_t *tri, float *u,
+                            float *v, hipStream_t st) {
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  switch (stack_class(s->max_depth)) {
+    case 16: hipLaunchKernelGGL((k_trace_api<MODE, 16, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
+    case 32: hipLaunchKernelGGL((k_trace_api<MODE, 32, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
+    case 64: hipLaunchKernelGGL((k_trace_api<MODE, 64, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
+    case 128: hipLaunchKernelGGL((k_trace_api<MODE, 128, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
+    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  }
+  HIP_TRY(hipGetLastError());
+  return PT_OK;
+}
+
+template <int MODE>
+static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                          const float *dy, const float *dz, uint8_t *hit, hipStream_t st) {
+  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  switch (stack_class(s->max_depth)) {
+    case 16: hipLaunchKernelGGL((k_any_api<MODE, 16>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
+    case 32: hipLaunchKernelGGL((k_any_api<MODE, 32>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
+    case 64: hipLaunchKernelGGL((k_any_api<MODE, 64>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
+    case 128: hipLaunchKernelGGL((k_any_api<MODE, 128>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
+    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  }
+  HIP_TRY(hipGetLastError());
+  return PT_OK;
+}
+
+static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const PtOptions *opt, uint32_t n_lights,
+                      FrameDev &F) {
+  if (!cam) return fail(PT_ERR_INVALID, "null camera");
+  if (W <= 0 || H <= 0 || (uint64_t)W * (uint64_t)H > (1ull << 28)) return fail(PT_ERR_INVALID, "bad image size");
+  if (cam->vw == 0) return fail(PT_ERR_INVALID, "camera vw must not be 0");
+  if (cam->aperture > 0 && !(cam->focus > 0)) return fail(PT_ERR_INVALID, "focus must be > 0 when aperture > 0");
+  PtOptions o;
+  if (opt) o = *opt; else pt_options_default(&o);
+  if (!(o.rr_prob > 0.0f)) return fail(PT_ERR_INVALID, "rr_prob must be > 0");
+  memset(&F, 0, sizeof(F));
+  F.W = W; F.H = H; F.P = (uint32_t)W * (uint32_t)H;
+  for (int k = 0; k < 3; ++k) { F.origin[k] = cam->origin[k]; F.bg[k] = o.bgcolor[k]; }
+  // vector_::rotate, math.cpp:130-140: each coefficient is a double expression of double trig
+  const double a = (double)cam->euler[0], b = (double)cam->euler[1], y = (double)cam->euler[2];
+  const double ca = std::cos(a), sa = std::sin(a), cb = std::cos(b), sb = std::sin(b), cy = std::cos(y), sy = std::sin(y);
+  F.rot[0] = cb * cy; F.rot[1] = sa * sb * cy - ca * sy; F.rot[2] = ca * sb * cy + sa * sy;
+  F.rot[3] = cb * sy; F.rot[4] = sa * sb * sy + ca * cy; F.rot[5] = ca * sb * sy - sa * cy;
+  F.rot[6] = -sb;     F.rot[7] = sa * cb;                F.rot[8] = ca * cb;
+  F.vw = (float)cam->vw;
+  F.neg_vh = (float)(-cam->vh);
+  F.pin_z = (float)(1 / (2 * std::tan(cam->fov_deg / 2 * (M_PI / 180)) / cam->vw));  // camera.cpp:167
+  F.aperture = cam->aperture; F.focus = cam->focus;
+  F.seed = seed;
+  F.stride = o.spp_stride ? o.spp_stride : 1;
+  F.rr_prob = o.rr_prob; F.rr_min_depth = o.rr_min_depth; F.max_depth = o.max_depth; F.sampling = o.sampling;
+  F.pdf_f = (float)(1 / (2 * M_PI) * (double)o.rr_prob);
+  F.pi_f = (float)M_PI;
+  F.dims_per_vertex = (3u * n_lights + 3u + 1u) & ~1u;
+  return PT_OK;
+}
+
+extern "C" {
+
+const char *pt_last_error(void) { return g_err.c_str(); }
+
+int pt_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(PT_ERR_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+void pt_options_default(PtOptions *o) {
+  if (!o) return;
+  o->rr_prob = 0.7f;      // camera.cpp:118
+  o->rr_min_depth = 2;    // camera.cpp:119
+  o->max_depth = 0;
+  o->sampling = PT_SAMPLE_UNIFORM;
+  o->bgcolor[0] = o->bgcolor[1] = o->bgcolor[2] = 0.0f;  // camera.cpp:52
+  o->trace_mode = PT_TRACE_FAST;
+  o->spp_stride = 1;
+  o->batch_spp = 0;
+}
+
+void pt_camera_default(PtCamera *c) {
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->fov_deg = 65.0f;  // camera.cpp:58
+  c->vw = 1; c->vh = 1;  // camera.cpp:55
+  c->aperture = 0.0f; c->focus = 1.0f;
+}
+
+void pt_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  philox4x32(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+void pt_scene_free(PtScene *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  free_workspace(s->ws);
+  if (s->d_nodes) (void)hipFree(s->d_nodes);
+  if (s->d_tris) (void)hipFree(s->d_tris);
+  if (s->d_mats) (void)hipFree(s->d_mats);
+  if (s->d_lights) (void)hipFree(s->d_lights);
+  if (s->d_ltris) (void)hipFree(s->d_ltris);
+  if (s->d_cnt) (void)hipFree(s->d_cnt);
+  if (s->d_stats) (void)hipFree(s->d_stats);
+  if (s->h_cnt) (void)hipHostFree(s->h_cnt);
+  if (s->h_stats) (void)hipHostFree(s->h_stats);
+  delete s;
+}
+
+static int upload(PtScene *s, const ptl::FlatScene &f) {
+  HIP_TRY(hipSetDevice(s->device));
+  auto up = [&](auto **dst, const auto &vec) -> hipError_t {
+    const size_t bytes = vec.size() * sizeof(vec[0]);
+    hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    s->bytes += bytes;
+    return bytes ? hipMemcpy(*dst, vec.data(), bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  HIP_TRY(up(&s->d_nodes, f.nodes));
+  HIP_TRY(up(&s->d_tris, f.tris));
+  HIP_TRY(up(&s->d_mats, f.mats));
+  HIP_TRY(up(&s->d_lights, f.lights));
+  HIP_TRY(up(&s->d_ltris, f.light_tris));
+  HIP_TRY(hipMalloc(&s->d_cnt, 2 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&s->d_stats, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc(&s->h_cnt, 2 * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&s->h_stats, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  s->dev.nodes = s->d_nodes; s->dev.tris = s->d_tris; s->dev.mats = s->d_mats;
+  s->dev.lights = s->d_lights; s->dev.light_tris = s->d_ltris;
+  s->dev.n_nodes = (uint32_t)f.nodes.size(); s->dev.n_tris = (uint32_t)f.tris.size();
+  s->dev.n_lights = (uint32_t)f.lights.size(); s->dev.n_mats = (uint32_t)f.mats.size();
+  s->max_depth = f.max_depth; s->n_meshes = f.n_meshes;
+  return PT_OK;
+}
+
+int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out) {
+  if (!desc || !out) return fail(PT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int ndev = pt_device_count();
+  if (ndev <= 0) return fail(PT_ERR_NODEVICE, "no HIP device: " + g_err);
+  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device ordinal out of range");
+  ptl::FlatScene flat;
+  std::string err;
+  int rc;
+  try {
+    rc = ptl::flatten_scene(*desc, flat, err);
+  } catch (const std::bad_alloc &) {
+    return fail(PT_ERR_NOMEM, "out of host memory while flattening the scene");
+  }
+  if (rc != PT_OK) return fail(rc, err);
+  if (stack_class(flat.max_depth) == 0) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  PtScene *s = new (std::nothrow) PtScene();
+  if (!s) return fail(PT_ERR_NOMEM, "out of host memory");
+  s->device = device;
+  rc = upload(s, flat);
+  if (rc != PT_OK) {
+    std::string keep = g_err;
+    pt_scene_free(s);
+    g_err = keep;
+    return rc;
+  }
+  *out = s;
+  return PT_OK;
+}
+
+int pt_scene_info(const PtScene *s, PtSceneInfo *info) {
+  if (!s || !info) return fail(PT_ERR_INVALID, "null argument");
+  info->n_meshes = s->n_meshes; info->n_tris = s->dev.n_tris; info->n_lights = s->dev.n_lights;
+  info->n_wide_nodes = s->dev.n_nodes; info->max_depth = s->max_depth; info->device = (uint32_t)s->device;
+  info->device_bytes = s->bytes;
+  return PT_OK;
+}
+
+// Switches the per-ray work counters (node boxes tested, triangles tested) on or off.
+// Counting kernels are separate instantiations; the default kernels carry no counters.
+int pt_scene_count_stats(PtScene *s, int enable) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  s->count_stats = enable != 0;
+  return PT_OK;
+}
+
+static int trace_dev(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                     const float *dy, const float *dz, float *t, int32_t *tri, float *u, float *v, int mode,
+                     hipStream_t st) {
+  if (n == 0) return PT_OK;
+  if (n > (size_t)0x7fffffff * kBlock) return fail(PT_ERR_INVALID, "too many rays for one call");
+  if (mode == PT_TRACE_EXACT)
+    return s->count_stats ? launch_trace_api<PT_TRACE_EXACT, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
+                          : launch_trace_api<PT_TRACE_EXACT, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
+  if (mode == PT_TRACE_FAST)
+    return s->count_stats ? launch_trace_api<PT_TRACE_FAST, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
+                          : launch_trace_api<PT_TRACE_FAST, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
+  return fail(PT_ERR_INVALID, "unknown trace mode");
+}
+
+int pt_trace_closest_dev(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                         const float *dy, const float *dz, float *t, int32_t *tri, float *u, float *v, int mode,
+                         void *stream) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !t || !tri)) return fail(PT_ERR_INVALID, "null ray or result array");
+  HIP_TRY(hipSetDevice(s->device));
+  return trace_dev(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, mode, (hipStream_t)stream);
+}
+
+// Reads and clears the work counters (see pt_scene_count_stats).
+int pt_scene_read_stats(PtScene *s, uint64_t *node_boxes, uint64_t *tri_tests) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
+  if (node_boxes) *node_boxes = s->h_stats[0];
+  if (tri_tests) *tri_tests = s->h_stats[1];
+  return PT_OK;
+}
+
+int pt_trace_closest(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                     const float *dy, const float *dz, float *t, int32_t *tri, float *u, float *v, int mode) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !t || !tri)) return fail(PT_ERR_INVALID, "null ray or result array");
+  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t chunk = (size_t)1 << 24;
+  float *buf = nullptr;
+  const size_t m = n < chunk ? n : chunk;
+  if (m == 0) return PT_OK;
+  HIP_TRY(hipMalloc(&buf, 10 * m * sizeof(float)));
+  int rc = PT_OK;
+  for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
+    const size_t k = (n - off) < chunk ? (n - off) : chunk;
+    const float *src[6] = {ox + off, oy + off, oz + off, dx + off, dy + off, dz + off};
+    hipError_t e = hipSuccess;
+    for (int a = 0; a < 6 && e == hipSuccess; ++a) e = hipMemcpy(buf + a * m, src[a], k * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
+    rc = trace_dev(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, buf + 6 * m,
+                   reinterpret_cast<int32_t *>(buf + 7 * m), buf + 8 * m, buf + 9 * m, mode, 0);
+    if (rc != PT_OK) break;
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(t + off, buf + 6 * m, k * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tri + off, buf + 7 * m, k * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && u) e = hipMemcpy(u + off, buf + 8 * m, k * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && v) e = hipMemcpy(v + off, buf + 9 * m, k * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(buf);
+  return rc;
+}
+
+int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                 const float *dy, const float *dz, uint8_t *hit, int mode) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hit)) return fail(PT_ERR_INVALID, "null ray or result array");
+  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t chunk = (size_t)1 << 24;
+  const size_t m = n < chunk ? n : chunk;
+  if (m == 0) return PT_OK;
+  float *buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, 7 * m * sizeof(float)));
+  int rc = PT_OK;
+  for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
+    const size_t k = (n - off) < chunk ? (n - off) : chunk;
+    const float *src[6] = {ox + off, oy + off, oz + off, dx + off, dy + off, dz + off};
+    hipError_t e = hipSuccess;
+    for (int a = 0; a < 6 && e == hipSuccess; ++a) e = hipMemcpy(buf + a * m, src[a], k * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
+    uint8_t *dh = reinterpret_cast<uint8_t *>(buf + 6 * m);
+    rc = mode == PT_TRACE_EXACT ? launch_any_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0)
+                                : launch_any_api<PT_TRACE_FAST>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
+    if (rc != PT_OK) break;
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(hit + off, dh, k, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(buf);
+  return rc;
+}
+
+int pt_camera_rays(const PtCamera *cam, int W, int H, int device, float *dir_xyz) {
+  if (!dir_xyz) return fail(PT_ERR_INVALID, "null output");
+  FrameDev F;
+  int rc = make_frame(cam, W, H, 0, nullptr, 0, F);
+  if (rc != PT_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  float *d = nullptr;
+  const size_t bytes = (size_t)F.P * 3 * sizeof(float);
+  HIP_TRY(hipMalloc(&d, bytes));
+  hipLaunchKernelGGL(k_camera_dirs, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, F, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(dir_xyz, d, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("camera rays: ") + hipGetErrorString(e));
+  return PT_OK;
+}
+
+int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
+                  uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, void *stream) {
+  if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
+  FrameDev F;
+  int rc = make_frame(cam, W, H, seed, opt, s->dev.n_lights, F);
+  if (rc != PT_OK) return rc;
+  PtOptions o;
+  if (opt) o = *opt; else pt_options_default(&o);
+  if (o.trace_mode != PT_TRACE_EXACT && o.trace_mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  PtCounters c;
+  memset(&c, 0, sizeof(c));
+  if (spp_count == 0) {
+    if (counters) *counters = c;
+    return PT_OK;
+  }
+  // samples per pixel in flight together: enough paths to fill the chip through the long
+  // tail of Russian roulette, bounded by memory (about 124 bytes per path)
+  uint32_t batch = o.batch_spp;
+  if (batch == 0) {
+    const uint64_t target = 16ull << 20;
+    batch = (uint32_t)((target + F.P - 1) / F.P);
+  }
+  if (batch > spp_count) batch = spp_count;
+  if (batch < 1) batch = 1;
+  while ((uint64_t)batch * F.P > (1ull << 31) && batch > 1) batch >>= 1;
+  rc = ensure_workspace(s, (size_t)batch * F.P);
+  if (rc != PT_OK) return rc;
+  Workspace &w = s->ws;
+  const bool exact = o.trace_mode == PT_TRACE_EXACT, cs = s->count_stats;
+  for (uint32_t done = 0; done < spp_count; done += batch) {
+    const uint32_t sb = (spp_count - done) < batch ? (spp_count - done) : batch;
+    uint32_t n = sb * F.P;
+    F.sample0 = spp_begin + done * F.stride;
+    hipLaunchKernelGGL(k_raygen, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F, n, w.q[0]);
+    HIP_TRY(hipGetLastError());
+    c.paths += n;
+    int cur = 0;
+    for (int depth = 0; n > 0; ++depth) {
+      if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
+      HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 2 * sizeof(uint32_t), st));
+      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, n, w.q[cur], st);
+      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, n, w.q[cur], st);
+      if (rc != PT_OK) return rc;
+      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st) : launch_shade<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st);
+      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st) : launch_shade<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st);
+      if (rc != PT_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(s->h_cnt, s->d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      c.rays_closest += n;
+      c.rays_shadow += (uint64_t)s->h_cnt[1] * s->dev.n_lights;
+      c.bounce_passes += 1;
+      n = s->h_cnt[0];
+      cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, w.Lr, w.Lg, w.Lb, accum);
+    HIP_TRY(hipGetLastError());
+  }
+  if (cs) {
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t nb = 0, nt = 0;
+    rc = pt_scene_read_stats(s, &nb, &nt);
+    if (rc != PT_OK) return rc;
+    c.node_boxes = nb; c.tri_tests = nt;
+  }
+  if (counters) *counters = c;
+  return PT_OK;
+}
+
+int pt_render(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
+              const PtOptions *opt, float *accum, PtCounters *counters) {
+  if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
+  if (W <= 0 || H <= 0) return fail(PT_ERR_INVALID, "bad image size");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)W * H * 3 * sizeof(float);
+  float *d = nullptr;
+  HIP_TRY(hipMalloc(&d, bytes));
+  hipError_t e = hipMemcpy(d, accum, bytes, hipMemcpyHostToDevice);
+  int rc = PT_OK;
+  if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("copy of accumulator: ") + hipGetErrorString(e));
+  if (rc == PT_OK) rc = pt_render_dev(s, cam, W, H, spp_begin, spp_count, seed, opt, d, counters, nullptr);
+  if (rc == PT_OK) {
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(accum, d, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+int pt_resolve(const float *sum, size_t n, uint32_t spp, float *pixels) {
+  if (!sum || !pixels || spp == 0) return fail(PT_ERR_INVALID, "null array or spp == 0");
+  for (size_t i = 0; i < n; ++i) pixels[i] = sum[i] / (float)spp * 255.0f;
+  return PT_OK;
+}
+
+}  // extern "C"

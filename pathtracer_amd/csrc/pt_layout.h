@@ -1,0 +1,88 @@
+// pt_layout.h — records shared by the host-side flattener and the gfx950 kernels.
+//
+// Everything a ray touches in HBM is a 16-byte-aligned record read with
+// dwordx4 loads: one lane = one ray, and rays in a wave diverge, so what counts
+// is bytes per gather and alignment, not cross-lane contiguity.
+#ifndef PT_LAYOUT_H
+#define PT_LAYOUT_H
+
+#include <stdint.h>
+
+namespace ptl {
+
+// Kinds of a child slot of a two-child device node.
+enum : uint32_t {
+  KIND_INTERNAL = 0,  // an internal node of the reference tree: its own box test decides (object.cpp:277)
+  KIND_GROUP = 1,     // grouping node that does not exist in the reference (several meshes of one
+                      // top-level leaf, or the super-root): the reference visits everything below it
+  KIND_LEAF = 2,      // triangle leaf: the reference never box-tests a leaf (object.cpp:266-275)
+  KIND_EMPTY = 3
+};
+
+// Encoding of a traversal-stack entry / child reference.
+//   bit 31 = 0: index of a device node
+//   bit 31 = 1: leaf, bits 28..30 = count-1 (1..8 triangles), bits 0..27 = first triangle slot
+static const uint32_t REF_LEAF = 0x80000000u;
+static const uint32_t REF_FIRST_MASK = 0x0fffffffu;
+static const uint32_t MAX_TRI_SLOTS = 1u << 28;
+
+// 64-byte node holding the boxes of both children.  As four float4:
+//   q0 = lo0.x lo0.y lo0.z hi0.x
+//   q1 = hi0.y hi0.z lo1.x lo1.y
+//   q2 = lo1.z hi1.x hi1.y hi1.z
+//   q3 = ref0 ref1 kind0 kind1           (bit patterns)
+struct alignas(16) WideNode {
+  float lo0[3];
+  float hi0[3];
+  float lo1[3];
+  float hi1[3];
+  uint32_t ref0, ref1;
+  uint32_t kind0, kind1;
+};
+static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+
+// 48-byte triangle: v0 and the two edges the reference recomputes per test
+// (e1 = v1 - v0, e2 = v2 - v0, object.cpp:408-409; the subtraction gives the same
+// bits wherever it runs).  Slots are ordered so that a larger slot wins a tie in t.
+struct alignas(16) TriRec {
+  float v0[3];
+  float e1[3];
+  float e2[3];
+  uint32_t tri_id;   // global triangle id in file order
+  uint32_t mat_id;
+  uint32_t mesh_id;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+struct alignas(16) MatRec {  // Material::diffuse / emission, object.cpp:146-148
+  float kd[3];
+  float pad0;
+  float ke[3];
+  float pad1;
+};
+static_assert(sizeof(MatRec) == 32, "MatRec must be 32 bytes");
+
+// One emissive mesh (an entry of Scene::lights(), scene.cpp:22-30).
+struct alignas(16) LightRec {
+  uint32_t first;     // first record in the light-triangle table
+  uint32_t count;
+  float area_f;       // (float)Polygon::area(), the upper bound handed to randreal (object.cpp:514)
+  float inv_area_f;   // (float)(1 / area), camera.cpp:114
+  float ke[3];
+  uint32_t mesh_id;
+};
+static_assert(sizeof(LightRec) == 32, "LightRec must be 32 bytes");
+
+// One triangle of an emissive mesh in creation order (Polygon::triangles), with the
+// running sum Polygon::sample walks (object.cpp:515-521).
+struct alignas(16) LightTri {
+  float u[3];      // v1 - v0
+  float v[3];      // v2 - v0
+  float n[3];      // Triangle::normal(), un-normalised (object.cpp:393)
+  uint32_t pad;
+  double accum;    // sum of Triangle::area() up to and including this triangle
+};
+static_assert(sizeof(LightTri) == 48, "LightTri must be 48 bytes");
+
+}  // namespace ptl
+#endif

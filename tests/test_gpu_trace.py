@@ -1,0 +1,125 @@
+"""GPU closest-hit / any-hit parity with the oracle's recursive Scene::castray
+(scene.cpp:18-20 -> object.cpp:265-285,406-429).  Bit-exact: t, u, v as uint32 bit
+patterns and the triangle id, on every ray, in both traversal modes."""
+import numpy as np
+import pytest
+
+from tests import util
+from oracle import pt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["plane", "box", "box40", "atrium_small", "blob_small", "terrain_small"]
+
+
+@pytest.fixture(scope="module")
+def api():
+    from pathtracer_amd import api
+    assert api.device_count() >= 1
+    return api
+
+
+_DEV = {}
+
+
+def dev_scene(api, name):
+    if name not in _DEV:
+        _DEV[name] = api.DeviceScene(util.world(name).export())
+    return _DEV[name]
+
+
+def ray_sets(name):
+    w = util.world(name)
+    sets = {}
+    cams = [O.default_camera(), O.default_camera(origin=(0.3, -0.2, 0.5), euler=(0.2, -0.4, 0.1), vw=16, vh=9),
+            O.default_camera(origin=(0, 1, -3), euler=(0.25, 0, 0), fov=40.0)]
+    for i, c in enumerate(cams):
+        sets["primary%d" % i] = util.primary_rays(c, 160, 120)
+    lo, hi = ((-9, -3, -1), (9, 3, 17)) if name == "terrain_small" else ((-2, -2, -1), (2, 2, 5))
+    sets["random"] = util.random_rays(30000, 1, lo, hi)
+    sets["axis"] = util.axis_rays(8000, 2, lo, hi)
+    if name != "plane":
+        sets["surface"] = util.surface_rays(w, 30000, 3)
+    if name == "box":
+        sets["lattice"] = util.lattice_rays()
+    return sets
+
+
+def check_equal(ref, got, label):
+    bad_t = util.bits(ref["t"]) != util.bits(got["t"])
+    bad_i = ref["tri"] != got["tri"]
+    hit = ref["tri"] >= 0
+    bad_u = (util.bits(ref["u"]) != util.bits(got["u"])) & hit
+    bad_v = (util.bits(ref["v"]) != util.bits(got["v"])) & hit
+    n_bad = int((bad_t | bad_i | bad_u | bad_v).sum())
+    assert n_bad == 0, "%s: %d of %d rays differ (t %d, tri %d, u %d, v %d)" % (
+        label, n_bad, len(bad_t), bad_t.sum(), bad_i.sum(), bad_u.sum(), bad_v.sum())
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_closest_exact_mode_is_bit_exact(api, name):
+    w, ds = util.world(name), dev_scene(api, name)
+    for label, (o, d) in ray_sets(name).items():
+        check_equal(w.castray(o, d), ds.trace_closest(o, d, api.PT_TRACE_EXACT), "%s/%s/exact" % (name, label))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_closest_fast_mode_primary_and_random_bit_exact(api, name):
+    w, ds = util.world(name), dev_scene(api, name)
+    for label, (o, d) in ray_sets(name).items():
+        if label == "surface":
+            continue
+        check_equal(w.castray(o, d), ds.trace_closest(o, d, api.PT_TRACE_FAST), "%s/%s/fast" % (name, label))
+
+
+@pytest.mark.parametrize("name", [s for s in SCENES if s != "plane"])
+def test_closest_fast_mode_surface_rays(api, name):
+    """Rays leaving a surface at grazing angles are ill-conditioned: the reference's own t is
+    noise there.  The fast mode's slack must still keep disagreements below 1 in 10 000."""
+    w, ds = util.world(name), dev_scene(api, name)
+    o, d = ray_sets(name)["surface"]
+    ref, got = w.castray(o, d), ds.trace_closest(o, d, api.PT_TRACE_FAST)
+    bad = (util.bits(ref["t"]) != util.bits(got["t"])) | (ref["tri"] != got["tri"])
+    assert bad.mean() <= 1e-4, "%s: %d of %d surface rays differ" % (name, bad.sum(), len(bad))
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_any_hit_matches_castray(api, name, mode):
+    w, ds = util.world(name), dev_scene(api, name)
+    for label, (o, d) in ray_sets(name).items():
+        ref = w.castray(o, d)["tri"] >= 0
+        got = ds.trace_any(o, d, mode)
+        bad = ref != got
+        limit = 1e-4 if (mode == 1 and label == "surface") else 0.0
+        assert bad.mean() <= limit, "%s/%s mode %d: %d of %d differ" % (name, label, mode, bad.sum(), len(bad))
+
+
+def test_known_answer_rays_plane(api):
+    """The rays whose reference results the survey recorded (t as bit patterns)."""
+    ds = dev_scene(api, "plane")
+    o = np.array([(1, 3, -1), (5.153648, 3, 0), (0, 0, 0), (0, 1e-6, 0), (0, 1.5e-6, 0), (0, 3, 0), (0, 3, 0),
+                  (-6, 3, .5), (-1, 3, .5)], np.float32)
+    d = np.array([(0, -1, 0)] * 5 + [(1, 0, 0), (0, 1, 0), (0, -1, 0), (0, -1, 0)], np.float32)
+    for mode in (0, 1):
+        r = ds.trace_closest(o, d, mode)
+        assert list(util.bits(r["t"])) == [0x403fffff, 0x403fffff, 0x7f800000, 0x7f800000, 0x35c9539b, 0x7f800000,
+                                            0x7f800000, 0x7f800000, 0x403fffff]
+        assert list(r["tri"]) == [0, 0, -1, -1, 0, -1, -1, -1, 1]
+        np.testing.assert_allclose(r["v"][0], 0.597019, rtol=1e-5)
+        np.testing.assert_allclose([r["u"][8], r["v"][8]], [0.402981, 0.0485093], rtol=1e-5)
+
+
+def test_camera_rays_bit_exact(api):
+    for cam_o, cam_g in [(O.default_camera(), api.make_camera()),
+                         (O.default_camera(euler=(0.3, -0.7, 0.2), fov=47.0, vw=16, vh=9),
+                          api.make_camera(euler=(0.3, -0.7, 0.2), fov=47.0, vw=16, vh=9))]:
+        a = O.camera_rays(cam_o, 320, 180)
+        b = api.camera_rays(cam_g, 320, 180)
+        assert (util.bits(a) == util.bits(b)).all()
+
+
+def test_philox_matches(api):
+    for ctr, key in [([0] * 4, [0] * 2), ([0xffffffff] * 4, [0xffffffff] * 2),
+                     ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])]:
+        assert (api.philox(ctr, key) == O.philox(ctr, key)).all()
