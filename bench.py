@@ -1,0 +1,215 @@
+"""Benchmark of the render hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--config box1k] [--spp S]
+
+One step = one frame: every pixel of the configuration's image gets `spp` camera paths,
+each followed through all its bounces (closest-hit rays + visibility rays), and the
+radiance sums are added to an accumulator that already lives in HBM.  With N > 1 each
+rank renders its own `spp` sample indices of the same frame (global index = rank + k*N,
+weak scaling) and one RCCL all-reduce merges the accumulators at frame end.
+
+Rank 0 prints ONE JSON line.  `value` is rays per second over all ranks (a ray = one
+Scene::castray-equivalent query: primary, bounce or visibility).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="box1k")
+    ap.add_argument("--spp", type=int, default=0, help="override the configuration's samples per pixel")
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-count", action="store_true", help="skip the instrumented pass (roofline becomes null)")
+    ap.add_argument("--max-depth", type=int, default=-1)
+    ap.add_argument("--aperture", type=float, default=-1.0)
+    return ap.parse_args()
+
+
+def workload(args):
+    from pathtracer_amd import scenes
+    if args.config not in scenes.CONFIGS or scenes.CONFIGS[args.config]["scene"] is None:
+        raise SystemExit("unknown or non-benchmark config %r" % args.config)
+    cfg = dict(scenes.CONFIGS[args.config])
+    if args.spp > 0:
+        cfg["spp"] = args.spp
+    return cfg
+
+
+def cpu_baseline(meshes, mats, cfg, cam_kw, opt_kw):
+    """The oracle (a port of the reference's CPU renderer: recursive estimator, mt19937,
+    rows handed to std::threads) timed on this box's host cores on a bounded sample of the
+    same workload."""
+    from oracle import pt_oracle as O
+    threads = min(16, O.hardware_threads())
+    w = O.World.from_meshes(meshes, mats)
+    cam = O.default_camera(**cam_kw)
+    opt = O.default_options(**opt_kw)
+    W, H = cfg["W"], cfg["H"]
+    t0 = time.perf_counter()
+    _, c1 = w.render(cam, W, H, 1, seed=1, opt=opt, rng=1, form=0, threads=threads)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(16, round(12.0 / max(t1, 1e-3)))))
+    t0 = time.perf_counter()
+    _, c = w.render(cam, W, H, spp, spp_begin=1, seed=1, opt=opt, rng=1, form=0, threads=threads)
+    dt = time.perf_counter() - t0
+    rays = c.rays_closest + c.rays_shadow
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "%dx%d, %d spp of the same scene and camera (%.1f s)" % (W, H, spp, dt),
+        "samples_per_s": c.paths / dt,
+        "ref_semantics_node_reads_per_ray": c.node_boxes / max(1, rays),
+        "ref_semantics_tri_tests_per_ray": c.tri_tests / max(1, rays),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, args.gpus))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import api, host
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = workload(args)
+    W, H, spp = cfg["W"], cfg["H"], cfg["spp"]
+    meshes, mats = cfg["scene"]()
+    scene = host.Scene.from_meshes(meshes, mats)
+    ds = scene.device_scene(local_rank)
+    cam_kw = dict(cfg["cam"])
+    if args.aperture >= 0:
+        cam_kw.update(aperture=args.aperture, focus=3.0)
+    cam = api.make_camera(**cam_kw)
+    opt_kw = dict(trace_mode=api.PT_TRACE_FAST if args.mode == "fast" else api.PT_TRACE_EXACT)
+    if args.max_depth >= 0:
+        opt_kw["max_depth"] = args.max_depth
+    opt = api.make_options(spp_stride=world, **opt_kw)
+    accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        accum.zero_()
+        c = ds.render_dev(cam, W, H, spp, accum.data_ptr(), spp_begin=rank, seed=0, opt=opt, stream=stream)
+        if world > 1:
+            dist.all_reduce(accum)
+        return c
+
+    # instrumented pass: node boxes and triangles the closest-hit kernel reads for exactly this
+    # frame (the sample indices are the same, so the counts are those of every timed step)
+    counts = None
+    if not args.no_count:
+        ds.count_stats(True)
+        counts = step()
+        torch.cuda.synchronize()
+        ds.count_stats(False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ds.profile(True)
+    ds.read_profile()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ds.read_profile()
+    ds.profile(False)
+
+    rays = last.rays_closest + last.rays_shadow
+    tot = torch.tensor([dt, float(rays), float(last.paths)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+    all_rays, all_paths = float(tot[1]), float(tot[2])
+    finite = bool(torch.isfinite(accum).all())
+
+    if rank == 0:
+        K = max(1, args.steps)
+        out = {
+            "metric": "Mrays/s at 1080p" if H == 1080 else "Mrays/s",
+            "value": all_rays * K / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%s: %d triangles in %d meshes, %d area light(s), %dx%d, %d spp per GPU, %s traversal"
+                            % (args.config, ds.info["n_tris"], ds.info["n_meshes"], ds.info["n_lights"], W, H, spp,
+                               args.mode),
+                "rays_per_sample": all_rays / max(1.0, all_paths),
+                "bounce_passes": int(last.bounce_passes),
+                "max_depth": opt.max_depth, "aperture": float(cam.aperture),
+            },
+            "samples_per_s": all_paths * K / dt,
+            "finite": finite,
+            "kernel_ms_per_step": {"trace_closest": prof["trace_ms"] / K, "shade_nee": prof["shade_ms"] / K,
+                                   "raygen_resolve": prof["other_ms"] / K},
+        }
+        if counts is not None:
+            # closest-hit kernel: algorithmic bytes = 32 B per node box + 36 B per triangle + 48 B of
+            # ray in / hit out per ray, over all launches of the timed steps
+            nb, nt, nr = counts.node_boxes, counts.tri_tests, counts.rays_closest
+            bytes_step = 32.0 * nb + 36.0 * nt + 48.0 * nr
+            launches = max(1, int(prof["trace_launches"]))
+            gbs = bytes_step * K / (prof["trace_ms"] * 1e-3) / 1e9 if prof["trace_ms"] > 0 else 0.0
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.config)
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    traffic = json.load(f).get("trace_closest_hbm_bytes_per_launch")
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_trace_queue (closest hit)",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_step * K / launches,
+                "avg_launch_ms": prof["trace_ms"] / launches, "launches": launches,
+                "node_boxes_per_ray": nb / max(1, nr), "tri_tests_per_ray": nt / max(1, nr),
+                "shadow_node_boxes_per_ray": counts.shadow_node_boxes / max(1, counts.rays_shadow),
+                "shadow_tri_tests_per_ray": counts.shadow_tri_tests / max(1, counts.rays_shadow),
+            }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(meshes, mats, cfg, cam_kw, {k: v for k, v in opt_kw.items() if k != "trace_mode"})
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

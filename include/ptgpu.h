@@ -122,10 +122,22 @@ typedef struct PtCounters {
   uint64_t paths;         /* camera paths started */
   uint64_t rays_closest;  /* closest-hit queries (primary + bounce), camera.cpp:64 */
   uint64_t rays_shadow;   /* visibility queries, camera.cpp:101 */
-  uint64_t node_boxes;    /* 32-byte node boxes tested (0 unless the library was built with counters) */
-  uint64_t tri_tests;     /* triangles tested (same) */
+  uint64_t node_boxes;    /* 32-byte node boxes tested by closest-hit queries (0 unless counting is on) */
+  uint64_t tri_tests;     /* triangles tested by closest-hit queries (same) */
   uint64_t bounce_passes; /* kernel passes over the path queue */
+  uint64_t shadow_node_boxes; /* node boxes tested by visibility queries (0 unless counting is on) */
+  uint64_t shadow_tri_tests;  /* triangles tested by visibility queries (same) */
 } PtCounters;
+
+/* Device time of the render kernels, measured with HIP events on the stream the
+ * kernels run on (see pt_scene_profile). */
+typedef struct PtProfile {
+  double trace_ms;        /* closest-hit kernel, summed over launches */
+  double shade_ms;        /* shading kernel (light loop with its visibility rays, roulette, compaction) */
+  double other_ms;        /* ray generation + resolve */
+  uint64_t trace_launches;
+  uint64_t shade_launches;
+} PtProfile;
 
 const char *pt_last_error(void);
 
@@ -152,6 +164,11 @@ int pt_scene_count_stats(PtScene *scene, int enable);
 /* Waits for the device, returns the counters gathered since the last read and
  * clears them.  Either pointer may be null. */
 int pt_scene_read_stats(PtScene *scene, uint64_t *node_boxes, uint64_t *tri_tests);
+/* Per-kernel device timing of pt_render / pt_render_dev: off by default; when on, every
+ * kernel launch is bracketed by HIP events.  pt_scene_read_profile returns the sums since
+ * the last read and clears them. */
+int pt_scene_profile(PtScene *scene, int enable);
+int pt_scene_read_profile(PtScene *scene, PtProfile *out);
 
 /* Seam A, batched: result i equals Scene::castray((ox,oy,oz)[i], (dx,dy,dz)[i])
  * (scene.cpp:18-20 -> object.cpp:265-285,406-429).  tri = global triangle id in

@@ -35,7 +35,8 @@ class PtOptions(C.Structure):
 
 class PtCounters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
-                ("node_boxes", C.c_uint64), ("tri_tests", C.c_uint64), ("bounce_passes", C.c_uint64)]
+                ("node_boxes", C.c_uint64), ("tri_tests", C.c_uint64), ("bounce_passes", C.c_uint64),
+                ("shadow_node_boxes", C.c_uint64), ("shadow_tri_tests", C.c_uint64)]
 
 
 class OrcRenderArgs(C.Structure):

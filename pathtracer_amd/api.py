@@ -51,10 +51,16 @@ class PtOptions(C.Structure):
 
 class PtCounters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64),
-                ("node_boxes", C.c_uint64), ("tri_tests", C.c_uint64), ("bounce_passes", C.c_uint64)]
+                ("node_boxes", C.c_uint64), ("tri_tests", C.c_uint64), ("bounce_passes", C.c_uint64),
+                ("shadow_node_boxes", C.c_uint64), ("shadow_tri_tests", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class PtProfile(C.Structure):
+    _fields_ = [("trace_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double),
+                ("trace_launches", C.c_uint64), ("shade_launches", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("index_or_first", "<u4"), ("count", "<u4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3)])
@@ -63,7 +69,8 @@ MAT_DTYPE = np.dtype([("kd", "<f4", 3), ("ke", "<f4", 3)])
 # Every symbol include/ptgpu.h declares.
 EXPORTS = [
     "pt_last_error", "pt_device_count", "pt_options_default", "pt_camera_default", "pt_scene_upload",
-    "pt_scene_free", "pt_scene_info", "pt_scene_count_stats", "pt_scene_read_stats", "pt_trace_closest",
+    "pt_scene_free", "pt_scene_info", "pt_scene_count_stats", "pt_scene_read_stats", "pt_scene_profile",
+    "pt_scene_read_profile", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_trace_any", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
     "pt_philox4x32",
 ]
@@ -93,6 +100,8 @@ def lib():
         L.pt_scene_info.argtypes = [C.c_void_p, C.POINTER(PtSceneInfo)]
         L.pt_scene_count_stats.argtypes = [C.c_void_p, C.c_int]
         L.pt_scene_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.pt_scene_profile.argtypes = [C.c_void_p, C.c_int]
+        L.pt_scene_read_profile.argtypes = [C.c_void_p, C.POINTER(PtProfile)]
         L.pt_trace_closest.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 10 + [C.c_int]
         L.pt_trace_closest_dev.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
         L.pt_trace_any.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.c_int]
@@ -197,10 +206,23 @@ class DeviceScene:
         _check(lib().pt_scene_info(self._h, C.byref(info)))
         self.info = {k: int(getattr(info, k)) for k, _ in info._fields_}
 
+    @classmethod
+    def borrow(cls, handle, device, owner=None):
+        """Wraps a PtScene* owned by someone else (it is not freed here)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(handle)
+        self._owned = False
+        self._owner = owner
+        self.device = device
+        info = PtSceneInfo()
+        _check(lib().pt_scene_info(self._h, C.byref(info)))
+        self.info = {k: int(getattr(info, k)) for k, _ in info._fields_}
+        return self
+
     def close(self):
-        if self._h:
+        if self._h and getattr(self, "_owned", True):
             lib().pt_scene_free(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -219,6 +241,14 @@ class DeviceScene:
         a, b = C.c_uint64(), C.c_uint64()
         _check(lib().pt_scene_read_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def profile(self, enable):
+        _check(lib().pt_scene_profile(self._h, int(enable)))
+
+    def read_profile(self):
+        p = PtProfile()
+        _check(lib().pt_scene_read_profile(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in p._fields_}
 
     @staticmethod
     def _cols(o, d):

@@ -1,0 +1,102 @@
+// main.cpp — headless render driver: what RenderThread::run does in the reference's GUI
+// (main.cpp:40-52: render 16 samples with a per-pass callback that converts `pixels` to an
+// image), without Qt.  Scene path, image size, samples and camera come from the command
+// line; the defaults are the reference's literals (main.cpp:28,42; camera.cpp:51,55,58).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "camera.h"
+
+using namespace pt;
+
+static void usage(const char *argv0) {
+  std::fprintf(stderr,
+               "usage: %s scene.obj [-o out.ppm] [--spp N] [--width W] [--height H] [--vw A --vh B]\n"
+               "          [--origin x,y,z] [--euler a,b,c] [--fov deg] [--aperture r --focus d]\n"
+               "          [--max-depth k] [--cosine] [--exact] [--seed s] [--device i] [--progress]\n",
+               argv0);
+}
+
+static bool parse3(const char *s, vec &v) { return std::sscanf(s, "%f,%f,%f", &v.x, &v.y, &v.z) == 3; }
+
+// The display conversion of the GUI callback (main.cpp:43-47): clamp((int)value, 0, 255).
+static void write_display_ppm(const Camera &cam, const std::string &path) {
+  std::ofstream ofs(path, std::ios::binary);
+  ofs << "P6\n" << cam.OUTW << " " << cam.OUTH << "\n255\n";
+  auto norm = [](double i) { return (unsigned char)std::clamp((int)i, 0, 255); };
+  for (const vec &p : cam.pixels) {
+    const unsigned char rgb[3] = {norm(p.x), norm(p.y), norm(p.z)};
+    ofs.write(reinterpret_cast<const char *>(rgb), 3);
+  }
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) {
+    usage(argv[0]);
+    return 2;
+  }
+  std::string scene_path = argv[1], out_path = "out.ppm";
+  int spp = 16;
+  bool progress = false, display = false;
+  Camera cam(vec(0, 0, 0));
+  for (int i = 2; i < argc; ++i) {
+    auto need = [&](const char *flag) -> const char * {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "%s needs a value\n", flag);
+        std::exit(2);
+      }
+      return argv[++i];
+    };
+    const std::string a = argv[i];
+    if (a == "-o") out_path = need("-o");
+    else if (a == "--spp") spp = std::atoi(need("--spp"));
+    else if (a == "--width") cam.OUTW = std::atoi(need("--width"));
+    else if (a == "--height") cam.OUTH = std::atoi(need("--height"));
+    else if (a == "--vw") cam.vw = std::atoi(need("--vw"));
+    else if (a == "--vh") cam.vh = std::atoi(need("--vh"));
+    else if (a == "--fov") cam.fov = (scalar)std::atof(need("--fov"));
+    else if (a == "--aperture") cam.aperture = (scalar)std::atof(need("--aperture"));
+    else if (a == "--focus") cam.focus = (scalar)std::atof(need("--focus"));
+    else if (a == "--max-depth") cam.options.max_depth = std::atoi(need("--max-depth"));
+    else if (a == "--seed") cam.seed = std::strtoull(need("--seed"), nullptr, 10);
+    else if (a == "--device") cam.device = std::atoi(need("--device"));
+    else if (a == "--cosine") cam.options.sampling = PT_SAMPLE_COSINE;
+    else if (a == "--exact") cam.options.trace_mode = PT_TRACE_EXACT;
+    else if (a == "--progress") progress = true;
+    else if (a == "--display") display = true;
+    else if (a == "--origin") { if (!parse3(need("--origin"), cam.origin)) { usage(argv[0]); return 2; } }
+    else if (a == "--euler") { if (!parse3(need("--euler"), cam.direction)) { usage(argv[0]); return 2; } }
+    else { usage(argv[0]); return 2; }
+  }
+  pt::verbose = true;
+  ParsedScene parsed;
+  std::string err;
+  if (!parseobj(scene_path, parsed, err)) {
+    std::fprintf(stderr, "%s\n", err.c_str());
+    return 1;
+  }
+  try {
+    Scene scene(std::move(parsed));
+    std::printf("%zu meshes, %zu triangles, %zu lights\n", scene.meshes.size(), scene.triangle_count(), scene.lights().size());
+    const auto t0 = std::chrono::steady_clock::now();
+    int pass = 0;
+    if (progress)
+      cam.render(scene, spp, [&]() { std::printf("pass %d/%d\n", ++pass, spp); });
+    else
+      cam.render(scene, spp);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double rays = (double)(cam.counters.rays_closest + cam.counters.rays_shadow);
+    std::printf("%.3f s, %.2f M samples/s, %.2f Mrays/s\n", secs, cam.counters.paths / secs * 1e-6, rays / secs * 1e-6);
+    if (display) write_display_ppm(cam, out_path);
+    else cam.save(out_path);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

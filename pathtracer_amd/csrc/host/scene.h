@@ -1,0 +1,57 @@
+// scene.h — host-side Scene: the reference's `scene` module (scene.cpp) with the ray
+// queries answered by the GPU library.
+#ifndef PT_HOST_SCENE_H
+#define PT_HOST_SCENE_H
+
+#include <string>
+#include <vector>
+
+#include "object.h"
+
+namespace pt {
+
+class Scene {
+ public:
+  std::vector<Polygon> meshes;      // creation ("file") order
+  std::vector<Material> materials;
+  BVH objects;                      // top-level tree over the meshes (scene.cpp:13); objects.objects
+                                    // holds mesh ids in the order the build left them
+
+  Scene() = default;
+  // Scene::Scene (scene.cpp:15): takes the parsed meshes and builds the top-level tree.
+  explicit Scene(ParsedScene &&parsed);
+  Scene(const Scene &) = delete;
+  Scene &operator=(const Scene &) = delete;
+  Scene(Scene &&o) noexcept;
+  Scene &operator=(Scene &&o) noexcept;
+  ~Scene();
+
+  // Scene::castray (scene.cpp:18-20) for one ray, answered by the device.  Uploads the
+  // scene on first use.  Throws std::runtime_error when the device call fails.
+  HitData castray(vec origin, vec direction) const;
+  // The same for n rays at once (structure-of-arrays results).
+  void castrays(size_t n, const vec *origin, const vec *direction, HitData *out, int mode = PT_TRACE_FAST) const;
+
+  // Scene::lights (scene.cpp:22-30): ids of emissive meshes in top-level object order.
+  std::vector<int> lights() const;
+
+  size_t triangle_count() const;
+  // Fills a PtSceneDesc whose pointers refer to storage owned by this Scene.
+  const PtSceneDesc &desc() const;
+  // Device copy (created on first use on `device`).
+  PtScene *device_scene(int device = 0) const;
+
+ private:
+  void build_desc() const;
+  mutable bool desc_ready_ = false;
+  mutable PtSceneDesc desc_{};
+  mutable std::vector<uint32_t> blas_node_offset_, tri_offset_, blas_order_, mesh_material_;
+  mutable std::vector<PtNode> blas_nodes_;
+  mutable std::vector<float> tri_verts_;
+  mutable std::vector<PtMaterial> mats_;
+  mutable PtScene *dev_ = nullptr;
+  mutable int dev_ordinal_ = -1;
+};
+
+}  // namespace pt
+#endif

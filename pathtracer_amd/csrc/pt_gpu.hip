@@ -328,8 +328,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev S, FrameDev F, int de
     Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
   }
   if (COUNT) {
-    wave_add64(stats + 0, nb);
-    wave_add64(stats + 1, nt);
+    wave_add64(stats + 2, nb);
+    wave_add64(stats + 3, nt);
   }
 }
 
@@ -384,10 +384,13 @@ struct PtScene {
   uint64_t bytes = 0;
   Workspace ws;
   uint32_t *d_cnt = nullptr;               // 2 words per pass
-  unsigned long long *d_stats = nullptr;   // node boxes, triangle tests
+  unsigned long long *d_stats = nullptr;   // node boxes, triangle tests: closest [0,1], visibility [2,3]
   uint32_t *h_cnt = nullptr;               // pinned
   unsigned long long *h_stats = nullptr;   // pinned
   bool count_stats = false;
+  bool profile = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  PtProfile prof{};
 };
 
 static int stack_class(uint32_t depth) {
@@ -565,6 +568,8 @@ void pt_scene_free(PtScene *s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->h_cnt) (void)hipHostFree(s->h_cnt);
   if (s->h_stats) (void)hipHostFree(s->h_stats);
+  for (int k = 0; k < 4; ++k)
+    if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
   delete s;
 }
 
@@ -583,10 +588,10 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(up(&s->d_lights, f.lights));
   HIP_TRY(up(&s->d_ltris, f.light_tris));
   HIP_TRY(hipMalloc(&s->d_cnt, 2 * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(&s->d_stats, 2 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&s->d_stats, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc(&s->h_cnt, 2 * sizeof(uint32_t), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc(&s->h_stats, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&s->h_stats, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   s->dev.nodes = s->d_nodes; s->dev.tris = s->d_tris; s->dev.mats = s->d_mats;
   s->dev.lights = s->d_lights; s->dev.light_tris = s->d_ltris;
   s->dev.n_nodes = (uint32_t)f.nodes.size(); s->dev.n_tris = (uint32_t)f.tris.size();
@@ -664,15 +669,40 @@ int pt_trace_closest_dev(PtScene *s, size_t n, const float *ox, const float *oy,
   return trace_dev(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, mode, (hipStream_t)stream);
 }
 
+static int read_stats4(PtScene *s, uint64_t out[4]) {
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
+  for (int k = 0; k < 4; ++k) out[k] = s->h_stats[k];
+  return PT_OK;
+}
+
 // Reads and clears the work counters (see pt_scene_count_stats).
 int pt_scene_read_stats(PtScene *s, uint64_t *node_boxes, uint64_t *tri_tests) {
   if (!s) return fail(PT_ERR_INVALID, "null scene");
+  uint64_t v[4];
+  int rc = read_stats4(s, v);
+  if (rc != PT_OK) return rc;
+  if (node_boxes) *node_boxes = v[0] + v[2];
+  if (tri_tests) *tri_tests = v[1] + v[3];
+  return PT_OK;
+}
+
+int pt_scene_profile(PtScene *s, int enable) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(unsigned long long)));
-  if (node_boxes) *node_boxes = s->h_stats[0];
-  if (tri_tests) *tri_tests = s->h_stats[1];
+  if (enable)
+    for (int k = 0; k < 4; ++k)
+      if (!s->ev[k]) HIP_TRY(hipEventCreate(&s->ev[k]));
+  s->profile = enable != 0;
+  return PT_OK;
+}
+
+int pt_scene_read_profile(PtScene *s, PtProfile *out) {
+  if (!s || !out) return fail(PT_ERR_INVALID, "null argument");
+  *out = s->prof;
+  memset(&s->prof, 0, sizeof(s->prof));
   return PT_OK;
 }
 
@@ -787,40 +817,69 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
   if (rc != PT_OK) return rc;
   Workspace &w = s->ws;
   const bool exact = o.trace_mode == PT_TRACE_EXACT, cs = s->count_stats;
+  const bool prof = s->profile;
+  auto elapsed = [&](int a, int b, double &acc) -> int {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[a], s->ev[b]));
+    acc += (double)ms;
+    return PT_OK;
+  };
   for (uint32_t done = 0; done < spp_count; done += batch) {
     const uint32_t sb = (spp_count - done) < batch ? (spp_count - done) : batch;
     uint32_t n = sb * F.P;
     F.sample0 = spp_begin + done * F.stride;
+    if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
     hipLaunchKernelGGL(k_raygen, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F, n, w.q[0]);
     HIP_TRY(hipGetLastError());
+    if (prof) {
+      HIP_TRY(hipEventRecord(s->ev[3], st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if ((rc = elapsed(0, 3, s->prof.other_ms)) != PT_OK) return rc;
+    }
     c.paths += n;
     int cur = 0;
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
       HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 2 * sizeof(uint32_t), st));
+      if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
       if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, n, w.q[cur], st);
       else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, n, w.q[cur], st);
       if (rc != PT_OK) return rc;
+      if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
       if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st) : launch_shade<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st);
       else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st) : launch_shade<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st);
       if (rc != PT_OK) return rc;
+      if (prof) HIP_TRY(hipEventRecord(s->ev[2], st));
       HIP_TRY(hipMemcpyAsync(s->h_cnt, s->d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
+      if (prof) {
+        if ((rc = elapsed(0, 1, s->prof.trace_ms)) != PT_OK) return rc;
+        if ((rc = elapsed(1, 2, s->prof.shade_ms)) != PT_OK) return rc;
+        s->prof.trace_launches += 1;
+        s->prof.shade_launches += 1;
+      }
       c.rays_closest += n;
       c.rays_shadow += (uint64_t)s->h_cnt[1] * s->dev.n_lights;
       c.bounce_passes += 1;
       n = s->h_cnt[0];
       cur ^= 1;
     }
+    if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
     hipLaunchKernelGGL(k_resolve, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, w.Lr, w.Lg, w.Lb, accum);
     HIP_TRY(hipGetLastError());
+    if (prof) {
+      HIP_TRY(hipEventRecord(s->ev[3], st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if ((rc = elapsed(0, 3, s->prof.other_ms)) != PT_OK) return rc;
+    }
   }
   if (cs) {
     HIP_TRY(hipStreamSynchronize(st));
-    uint64_t nb = 0, nt = 0;
-    rc = pt_scene_read_stats(s, &nb, &nt);
+    uint64_t v[4];
+    rc = read_stats4(s, v);
     if (rc != PT_OK) return rc;
-    c.node_boxes = nb; c.tri_tests = nt;
+    c.node_boxes = v[0]; c.tri_tests = v[1];
+    c.shadow_node_boxes = v[2]; c.shadow_tri_tests = v[3];
   }
   if (counters) *counters = c;
   return PT_OK;
