@@ -71,8 +71,14 @@ struct PathRng {
     sample = s;
     block = 0xffffffffu;
   }
+  uint32_t cheap = 0;
   __device__ __forceinline__ double u01(uint32_t dim) {
     const uint32_t b = dim >> 1;
+    if (cheap) {
+      uint32_t h = (pixel * 0x9E3779B9u) ^ (sample * 0x85EBCA6Bu) ^ (dim * 0xC2B2AE35u);
+      h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+      return (double)(h >> 8) * (1.0 / 16777216.0);
+    }
     if (b != block) {
       philox4x32(pixel, sample, b, 0u, k0, k1, w);
       block = b;
@@ -102,6 +108,8 @@ struct HitRec {
   float t;
   uint32_t slot;  // 0xffffffff = miss
   float u, v;
+  V3 n;           // Triangle::normal() of the hit triangle, un-normalised (only with WANT_N)
+  uint32_t mat;   // its material id (only with WANT_N)
 };
 
 // Slack of the optional tests of the fast mode (a relative 2^-12 plus a small
@@ -112,10 +120,7 @@ struct HitRec {
 
 // Möller–Trumbore exactly as Triangle::intersect evaluates it (object.cpp:406-429).
 // Returns true when the reference would return a hit.
-__device__ __forceinline__ bool tri_test(const ptl::TriRec *__restrict__ tris, uint32_t slot, V3 o, V3 d,
-                                         float &t, float &u, float &v) {
-  const float4 *p = reinterpret_cast<const float4 *>(tris + slot);
-  const float4 a = p[0], b = p[1], c = p[2];
+__device__ __forceinline__ bool tri_test(float4 a, float4 b, float4 c, V3 o, V3 d, float &t, float &u, float &v) {
   const V3 v0 = mk(a.x, a.y, a.z);
   const V3 e1 = mk(a.w, b.x, b.y);
   const V3 e2 = mk(b.z, b.w, c.x);
@@ -134,14 +139,56 @@ __device__ __forceinline__ bool tri_test(const ptl::TriRec *__restrict__ tris, u
   return true;
 }
 
+// The part of the scene a workgroup keeps in LDS: the first n_nodes nodes (the tree is
+// numbered breadth-first from the root, so these are its top levels) and, when the whole
+// triangle table fits, all triangles.  Both are stored split by 16-byte piece: piece k of
+// node i at nodes[k*n_nodes + i], piece k of triangle i at tris[k*n_tris + i].  Rays of a wave diverge, so every node or triangle
+// fetch is 64 separate 16-byte requests; out of LDS such a gather costs a few cycles, out
+// of the vector cache at least one cycle per lane.
+//
+// The copy lives in the kernel's dynamic LDS block and is addressed by offsets into it, not
+// through pointers: a pointer that travels through a struct loses its address space and the
+// compiler falls back to flat loads (measured: three times the memory instructions).
+extern __shared__ float4 pt_smem[];
+
+// Loads and stores with the address space spelled out, so that a value that may come from
+// LDS or from global memory is never fetched through a merged (flat) pointer.
+typedef float pt_f4 __attribute__((ext_vector_type(4)));
+typedef const pt_f4 __attribute__((address_space(3))) *pt_lds_cf4;
+typedef uint32_t __attribute__((address_space(3))) *pt_lds_u32;
+typedef const pt_f4 __attribute__((address_space(1))) *pt_glb_cf4;
+__device__ __forceinline__ float4 lds_f4(uint32_t i) {
+  const pt_f4 v = ((pt_lds_cf4)pt_smem)[i];
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 glb_f4(const void *base, size_t i) {
+  const pt_f4 v = ((pt_glb_cf4)base)[i];
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t stack_get(uint32_t w) { return ((pt_lds_u32)pt_smem)[w]; }
+__device__ __forceinline__ void stack_put(uint32_t w, uint32_t v) { ((pt_lds_u32)pt_smem)[w] = v; }
+
+struct LdsScene {
+  uint32_t node_base;  // offset of piece 0 of node 0 in pt_smem, in float4
+  uint32_t tri_base;   // offset of piece 0 of triangle 0
+  uint32_t n_nodes;
+  uint32_t n_tris;
+};
+
 // Walks the tree for one ray.  MODE: PT_TRACE_EXACT reaches exactly the leaves the
 // reference reaches; PT_TRACE_FAST additionally skips leaves and groups whose box
 // the ray misses (with slack) and subtrees that start beyond the best hit (with
 // slack), and descends near child first.  ANY: stop at the first accepted triangle.
-// `stk` is this lane's column of the LDS stack (entries `stride` apart).
-template <int MODE, bool ANY, bool COUNT>
-__device__ __forceinline__ bool walk(const SceneDev &S, V3 o, V3 d, uint32_t *stk, int stride, HitRec &best,
-                                     uint32_t &n_boxes, uint32_t &n_tris) {
+// `stk` is the offset (in 32-bit words of the kernel's LDS block) of this lane's stack
+// column; entries are `stride` words apart.
+//
+// Shape: one loop whose step is either a node (two child boxes) or a leaf (its triangles),
+// so every step advances every live lane.  A nested "nodes until a leaf, then the leaf"
+// shape was measured twice as slow: the wave then takes the longest node run of any lane
+// in every round, and node steps are the expensive ones.
+template <int MODE, bool ANY, bool COUNT, bool WANT_N = false>
+__device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o, V3 d, uint32_t stk, uint32_t stride,
+                                     HitRec &best, uint32_t &n_boxes, uint32_t &n_tris) {
   const float qnan = __builtin_nanf("");
   // 1/d per axis as AABB::intersect forms it (object.cpp:183); an axis with d == 0 is
   // skipped there, which a NaN reciprocal reproduces: NaN never updates tmin/tmax.
@@ -153,14 +200,28 @@ __device__ __forceinline__ bool walk(const SceneDev &S, V3 o, V3 d, uint32_t *st
   best.slot = 0xffffffffu;
   best.u = 0.0f;
   best.v = 0.0f;
+  if (WANT_N) {
+    best.n = mk(0.0f, 0.0f, 0.0f);
+    best.mat = 0u;
+  }
   float cull = __builtin_inff();
   uint32_t cur = 0;
   int sp = 0;
   for (;;) {
     if (!(cur & ptl::REF_LEAF)) {
-      const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur);
-      const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-      const uint4 q3 = *reinterpret_cast<const uint4 *>(p + 3);
+      float4 q0, q1, q2;
+      uint4 q3;
+      if (cur < C.n_nodes) {
+        const uint32_t at = C.node_base + cur;
+        q0 = lds_f4(at); q1 = lds_f4(at + C.n_nodes); q2 = lds_f4(at + 2u * C.n_nodes);
+        const float4 r = lds_f4(at + 3u * C.n_nodes);
+        q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+      } else {
+        const size_t at = 4u * (size_t)cur;
+        q0 = glb_f4(S.nodes, at); q1 = glb_f4(S.nodes, at + 1); q2 = glb_f4(S.nodes, at + 2);
+        const float4 r = glb_f4(S.nodes, at + 3);
+        q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+      }
       if (COUNT) n_boxes += 2;
       // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
       float tn0 = 1e-5f, tf0 = __builtin_inff(), tn1 = 1e-5f, tf1 = __builtin_inff();
@@ -199,7 +260,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, V3 o, V3 d, uint32_t *st
       }
       if (p0 && p1) {
         const bool swap = (MODE == PT_TRACE_FAST && !ANY) ? (tn1 < tn0) : false;
-        stk[sp * stride] = swap ? q3.x : q3.y;
+        stack_put(stk + (uint32_t)sp * stride, swap ? q3.x : q3.y);
         ++sp;
         cur = swap ? q3.y : q3.x;
         continue;
@@ -209,10 +270,19 @@ __device__ __forceinline__ bool walk(const SceneDev &S, V3 o, V3 d, uint32_t *st
     } else {
       const uint32_t first = cur & ptl::REF_FIRST_MASK;
       const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      const bool in_lds = first + cnt <= C.n_tris;
       for (uint32_t k = 0; k < cnt; ++k) {
         float t, u, v;
         if (COUNT) ++n_tris;
-        if (tri_test(S.tris, first + k, o, d, t, u, v)) {
+        float4 ta, tb, tc;
+        if (in_lds) {
+          const uint32_t at = C.tri_base + first + k;
+          ta = lds_f4(at); tb = lds_f4(at + C.n_tris); tc = lds_f4(at + 2u * C.n_tris);
+        } else {
+          const size_t at = 3u * (size_t)(first + k);
+          ta = glb_f4(S.tris, at); tb = glb_f4(S.tris, at + 1); tc = glb_f4(S.tris, at + 2);
+        }
+        if (tri_test(ta, tb, tc, o, d, t, u, v)) {
           if (ANY) return true;
           // larger slot wins a tie: the reference's leftmost-in-leaf / right-sibling rule
           if (t < best.t || (t == best.t && (int32_t)(first + k) > (int32_t)best.slot)) {
@@ -220,6 +290,10 @@ __device__ __forceinline__ bool walk(const SceneDev &S, V3 o, V3 d, uint32_t *st
             best.slot = first + k;
             best.u = u;
             best.v = v;
+            if (WANT_N) {
+              best.n = cross(mk(ta.w, tb.x, tb.y), mk(tb.z, tb.w, tc.x));  // (v1-v0) x (v2-v0), object.cpp:393
+              best.mat = __float_as_uint(tc.z);
+            }
             if (MODE == PT_TRACE_FAST) cull = t + (t * PT_SLACK_REL + PT_SLACK_ABS);
           }
         }
@@ -227,7 +301,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, V3 o, V3 d, uint32_t *st
     }
     if (sp == 0) break;
     --sp;
-    cur = stk[sp * stride];
+    cur = stack_get(stk + (uint32_t)sp * stride);
   }
   return best.slot != 0xffffffffu;
 }

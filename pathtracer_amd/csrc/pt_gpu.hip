@@ -13,9 +13,11 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "pt_device.h"
@@ -25,13 +27,19 @@ using namespace ptd;
 
 // ===================================================================== device side
 
-static const int kBlock = 256;
+static const int kBlock = 256;  // block size of the streaming kernels (ray generation, resolve)
 
 struct QueueDev {  // one live path per index, arrays `cap` long
   float *ox, *oy, *oz, *dx, *dy, *dz;  // ray
   float *tx, *ty, *tz;                 // throughput
   float *lx, *ly, *lz;                 // radiance gathered so far
   uint32_t *id;                        // sample_in_batch * P + pixel
+};
+
+struct HitDev {  // closest hit of every queued ray
+  float *t;
+  float *nx, *ny, *nz;  // Triangle::normal() of the hit triangle, un-normalised
+  uint32_t *mat;
 };
 
 struct FrameDev {
@@ -51,6 +59,14 @@ struct FrameDev {
   float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
   float pi_f;            // (float)M_PI, camera.cpp:122
   uint32_t dims_per_vertex;
+  uint32_t debug;        // profiling experiments only (PT_DEBUG_FLAGS); 0 in normal use
+};
+
+// What a traversal kernel keeps in LDS (see LdsScene) and how many words of the
+// per-launch counter block it uses as its work-queue head.
+struct LdsPlan {
+  uint32_t n_nodes;  // top nodes staged in LDS
+  uint32_t n_tris;   // 0, or all triangles
 };
 
 __device__ __forceinline__ V3 rotate9(const double *c, V3 p) {
@@ -123,19 +139,66 @@ __device__ __forceinline__ void wave_add64(unsigned long long *dst, uint32_t v) 
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, (unsigned long long)s);
 }
 
-template <int MODE, int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_queue(SceneDev S, uint32_t n, QueueDev q, float *hit_t,
-                                                        uint32_t *hit_slot, unsigned long long *stats) {
-  __shared__ uint32_t stk[STACK * kBlock];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+// The traversal kernels are persistent: a launch holds at most as many workgroups as the
+// chip keeps resident, every workgroup stages its part of the scene into LDS once, and
+// every wave then pulls chunks of 64 rays from a shared counter until none are left.
+
+// The LDS copy is split by quarter: quarter k of node i sits at nodes[k*n_nodes + i] (and
+// third k of triangle i at tris[k*n_tris + i]).  A wave's 64 lanes then read 16-byte pieces
+// whose bank depends on i mod 16; with whole 64-byte records side by side only 4 of the 16
+// bank groups would ever be hit by one instruction.
+template <int BLOCK>
+__device__ __forceinline__ LdsScene stage_scene(const SceneDev &S, LdsPlan plan, uint32_t &stack_base) {
+  const float4 *gn = reinterpret_cast<const float4 *>(S.nodes);
+  const float4 *gt = reinterpret_cast<const float4 *>(S.tris);
+  LdsScene C;
+  C.node_base = 0;
+  C.tri_base = 4u * plan.n_nodes;
+  C.n_nodes = plan.n_nodes;
+  C.n_tris = plan.n_tris;
+  for (uint32_t i = threadIdx.x; i < 4u * plan.n_nodes; i += BLOCK) pt_smem[(i & 3u) * plan.n_nodes + (i >> 2)] = gn[i];
+  for (uint32_t i = threadIdx.x; i < 3u * plan.n_tris; i += BLOCK)
+    pt_smem[C.tri_base + (i % 3u) * plan.n_tris + (i / 3u)] = gt[i];
+  __syncthreads();
+  stack_base = 4u * (C.tri_base + 3u * plan.n_tris) + threadIdx.x;  // in 32-bit words
+  return C;
+}
+
+// Work is claimed in runs of `len` chunks of 64 items.  One returning atomic on a single
+// word sustains under 100 claims per microsecond chip-wide, so a claim per 64 rays would cap
+// a large launch at about 6 G rays/s on its own; a long run, on the other hand, serialises a
+// small launch on few waves.  The host picks `len` per launch (run_length()).
+// Returns the first chunk of the next run for this wave (all lanes must be active).
+__device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
+  uint32_t c = 0;
+  if ((threadIdx.x & 63) == 0) c = atomicAdd(head, len);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+}
+
+template <int MODE, int BLOCK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, QueueDev q, HitDev hit,
+                                                       uint32_t *head, unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const uint32_t lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0;
-  if (i < n) {
-    const V3 o = mk(q.ox[i], q.oy[i], q.oz[i]);
-    const V3 d = mk(q.dx[i], q.dy[i], q.dz[i]);
-    HitRec h;
-    walk<MODE, false, COUNT>(S, o, d, stk + threadIdx.x, kBlock, h, nb, nt);
-    hit_t[i] = h.t;
-    hit_slot[i] = h.slot;
+  for (;;) {
+    const uint32_t run = next_run(head, kRun);
+    if ((uint64_t)run * 64u >= n) break;
+    for (uint32_t c = 0; c < kRun; ++c) {
+      const uint32_t base = (run + c) * 64u;
+      if (base >= n) break;
+      const uint32_t i = base + lane;
+      if (i < n) {
+        const V3 o = mk(q.ox[i], q.oy[i], q.oz[i]);
+        const V3 d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        HitRec h;
+        walk<MODE, false, COUNT, true>(S, C, o, d, stk, BLOCK, h, nb, nt);
+        hit.t[i] = h.t;
+        hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
+        hit.mat[i] = h.mat;
+      }
+    }
   }
   if (COUNT) {
     wave_add64(stats + 0, nb);
@@ -143,23 +206,33 @@ __global__ __launch_bounds__(kBlock) void k_trace_queue(SceneDev S, uint32_t n, 
   }
 }
 
-template <int MODE, int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_api(SceneDev S, size_t n, const float *ox, const float *oy,
-                                                      const float *oz, const float *dx, const float *dy,
-                                                      const float *dz, float *t, int32_t *tri, float *u, float *v,
-                                                      unsigned long long *stats) {
-  __shared__ uint32_t stk[STACK * kBlock];
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+template <int MODE, int BLOCK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
+                                                     const float *oy, const float *oz, const float *dx,
+                                                     const float *dy, const float *dz, float *t, int32_t *tri,
+                                                     float *u, float *v, uint32_t *head, unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const uint32_t lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0;
-  if (i < n) {
-    const V3 o = mk(ox[i], oy[i], oz[i]);
-    const V3 d = mk(dx[i], dy[i], dz[i]);
-    HitRec h;
-    const bool hit = walk<MODE, false, COUNT>(S, o, d, stk + threadIdx.x, kBlock, h, nb, nt);
-    t[i] = h.t;
-    tri[i] = hit ? (int32_t)S.tris[h.slot].tri_id : -1;
-    if (u) u[i] = h.u;
-    if (v) v[i] = h.v;
+  for (;;) {
+    const uint32_t run = next_run(head, kRun);
+    if ((size_t)run * 64u >= n) break;
+    for (uint32_t c = 0; c < kRun; ++c) {
+      const size_t base = (size_t)(run + c) * 64u;
+      if (base >= n) break;
+      const size_t i = base + lane;
+      if (i < n) {
+        const V3 o = mk(ox[i], oy[i], oz[i]);
+        const V3 d = mk(dx[i], dy[i], dz[i]);
+        HitRec h;
+        const bool found = walk<MODE, false, COUNT, false>(S, C, o, d, stk, BLOCK, h, nb, nt);
+        t[i] = h.t;
+        tri[i] = found ? (int32_t)S.tris[h.slot].tri_id : -1;
+        if (u) u[i] = h.u;
+        if (v) v[i] = h.v;
+      }
+    }
   }
   if (COUNT) {
     wave_add64(stats + 0, nb);
@@ -167,19 +240,30 @@ __global__ __launch_bounds__(kBlock) void k_trace_api(SceneDev S, size_t n, cons
   }
 }
 
-template <int MODE, int STACK>
-__global__ __launch_bounds__(kBlock) void k_any_api(SceneDev S, size_t n, const float *ox, const float *oy,
-                                                    const float *oz, const float *dx, const float *dy,
-                                                    const float *dz, uint8_t *hit) {
-  __shared__ uint32_t stk[STACK * kBlock];
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  HitRec h;
-  uint32_t nb = 0, nt = 0;
-  hit[i] = walk<MODE, true, false>(S, mk(ox[i], oy[i], oz[i]), mk(dx[i], dy[i], dz[i]), stk + threadIdx.x, kBlock, h,
-                                   nb, nt)
-               ? 1
-               : 0;
+template <int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
+                                                   const float *oy, const float *oz, const float *dx, const float *dy,
+                                                   const float *dz, uint8_t *hit, uint32_t *head) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const uint32_t lane = threadIdx.x & 63;
+  for (;;) {
+    const uint32_t run = next_run(head, kRun);
+    if ((size_t)run * 64u >= n) break;
+    for (uint32_t c = 0; c < kRun; ++c) {
+      const size_t base = (size_t)(run + c) * 64u;
+      if (base >= n) break;
+      const size_t i = base + lane;
+      if (i < n) {
+        HitRec h;
+        uint32_t nb = 0, nt = 0;
+        hit[i] = walk<MODE, true, false, false>(S, C, mk(ox[i], oy[i], oz[i]), mk(dx[i], dy[i], dz[i]), stk, BLOCK,
+                                                h, nb, nt)
+                     ? 1
+                     : 0;
+      }
+    }
+  }
 }
 
 // random_direction, camera.cpp:77-90
@@ -206,131 +290,221 @@ __device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
   return add(add(scale(t1, lx), scale(t2, ly)), scale(n, lz));
 }
 
-// One path vertex.  cnt[0] = survivors written to `out`, cnt[1] = paths that hit something.
-template <int MODE, int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev S, FrameDev F, int depth, uint32_t n, QueueDev in,
-                                                  const float *hit_t, const uint32_t *hit_slot, QueueDev out,
-                                                  uint32_t *cnt, float *Lr, float *Lg, float *Lb,
-                                                  unsigned long long *stats) {
-  __shared__ uint32_t stk[STACK * kBlock];
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const bool active = i < n;
-  bool alive = false, did_hit = false;
-  V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
-  uint32_t id = 0;
-  uint32_t nb = 0, nt = 0;
-  if (active) {
-    id = in.id[i];
-    T = mk(in.tx[i], in.ty[i], in.tz[i]);
-    L = mk(in.lx[i], in.ly[i], in.lz[i]);
-    const float t = hit_t[i];
-    if (t == __builtin_inff()) {  // camera.cpp:65-66
-      L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
-    } else {
-      did_hit = true;
-      o = mk(in.ox[i], in.oy[i], in.oz[i]);
-      d = mk(in.dx[i], in.dy[i], in.dz[i]);
-      const uint32_t slot = hit_slot[i];
-      const float4 *tp = reinterpret_cast<const float4 *>(S.tris + slot);
-      const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-      const V3 e1 = mk(ta.w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tc.x);
-      const uint32_t mat_id = __float_as_uint(tc.z);
-      const V3 x = add(o, scale(d, t));                    // camera.cpp:68
-      V3 nrm = normalize(cross(e1, e2));                   // camera.cpp:69
-      if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);   // camera.cpp:72-73
-      const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
-      const float4 m0 = mp[0], m1 = mp[1];
-      const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
+// One path vertex per work item.  A surviving path is written back at its own index of `out`
+// and the chunk's 64-bit survivor mask to chunk_mask; k_scan_* and k_compact then pack the
+// survivors (a stable compaction: the queue stays in pixel order and no two launches differ).
+// Claiming an output slot per wave with an atomic on one counter instead was measured at
+// 260 ms per frame on its own: a single word takes under 100 atomics per microsecond.
+// cnt[1] = paths that hit something, cnt[3] = this kernel's work-queue head.
+template <int MODE, int BLOCK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth, uint32_t n,
+                                                 QueueDev in, HitDev hit, QueueDev out, unsigned long long *chunk_mask,
+                                                 uint32_t *cnt, float *Lr, float *Lg, float *Lb,
+                                                 unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const int lane = threadIdx.x & 63;
+  uint32_t nb = 0, nt = 0, n_hit = 0;
+  for (uint32_t run = next_run(cnt + 3, kRun), c = 0;; ++c) {
+    if (c == kRun) {
+      run = next_run(cnt + 3, kRun);
+      c = 0;
+    }
+    const uint32_t chunk_base = (run + c) * 64u;
+    if ((uint64_t)(run + c) * 64u >= n) break;
+    const uint32_t i = chunk_base + (uint32_t)lane;
+    const bool active = i < n;
+    bool alive = false, did_hit = false;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
+    uint32_t id = 0;
+    if (active) {
+      id = in.id[i];
+      T = mk(in.tx[i], in.ty[i], in.tz[i]);
+      L = mk(in.lx[i], in.ly[i], in.lz[i]);
+      const float t = hit.t[i];
+      if (t == __builtin_inff()) {  // camera.cpp:65-66
+        L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
+      } else {
+        did_hit = true;
+        o = mk(in.ox[i], in.oy[i], in.oz[i]);
+        d = mk(in.dx[i], in.dy[i], in.dz[i]);
+        const uint32_t mat_id = hit.mat[i];
+        const V3 x = add(o, scale(d, t));                               // camera.cpp:68
+        V3 nrm = normalize(mk(hit.nx[i], hit.ny[i], hit.nz[i]));        // camera.cpp:69
+        if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);              // camera.cpp:72-73
+        const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
+        const float4 m0 = mp[0], m1 = mp[1];
+        const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
 
-      PathRng rng;
-      rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
-      const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
+        PathRng rng;
+        rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
+        rng.cheap = F.debug & 4u;
+        const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
 
-      // direct light: every light at every vertex, camera.cpp:96-115
-      V3 local = mk(0, 0, 0);
-      for (uint32_t l = 0; l < S.n_lights; ++l) {
-        const float4 *lp = reinterpret_cast<const float4 *>(S.lights + l);
-        const float4 l0 = lp[0], l1 = lp[1];
-        const uint32_t first = __float_as_uint(l0.x), count = __float_as_uint(l0.y);
-        const float area_f = l0.z, inv_area_f = l0.w;
-        const V3 lke = mk(l1.x, l1.y, l1.z);
-        // Polygon::sample, object.cpp:513-523: first triangle whose running area reaches r
-        const double r = (double)rng.real(0.0f, area_f, base + 3u * l);
-        uint32_t lo = 0, hi = count - 1;  // past the end the reference is undefined; take the last
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (r <= S.light_tris[first + mid].accum) hi = mid; else lo = mid + 1;
+        // direct light: every light at every vertex, camera.cpp:96-115
+        V3 local = mk(0, 0, 0);
+        for (uint32_t l = 0; l < S.n_lights; ++l) {
+          const float4 *lp = reinterpret_cast<const float4 *>(S.lights + l);
+          const float4 l0 = lp[0], l1 = lp[1];
+          const uint32_t first = __float_as_uint(l0.x), count = __float_as_uint(l0.y);
+          const float area_f = l0.z, inv_area_f = l0.w;
+          const V3 lke = mk(l1.x, l1.y, l1.z);
+          // Polygon::sample, object.cpp:513-523: first triangle whose running area reaches r
+          const double r = (double)rng.real(0.0f, area_f, base + 3u * l);
+          uint32_t lo = 0, hi = count - 1;  // past the end the reference is undefined; take the last
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (r <= S.light_tris[first + mid].accum) hi = mid; else lo = mid + 1;
+          }
+          const float4 *qp = reinterpret_cast<const float4 *>(S.light_tris + first + lo);
+          const float4 g0 = qp[0], g1 = qp[1], g2 = qp[2];
+          const V3 lu = mk(g0.x, g0.y, g0.z), lv = mk(g0.w, g1.x, g1.y), ln = mk(g1.z, g1.w, g2.x);
+          // Triangle::sample, object.cpp:432-442 (the point is relative to v0; v0 is not added)
+          const double s = (double)rng.real(0.0f, 1.0f, base + 3u * l + 1u);
+          const double tt = (double)rng.real(0.0f, 1.0f, base + 3u * l + 2u);
+          V3 point;
+          if (s + tt <= 1.0) point = add(scale(lu, (float)s), scale(lv, (float)tt));
+          else point = add(scale(lu, (float)(1.0 - s)), scale(lv, (float)(1.0 - tt)));
+          const V3 to = normalize(sub(point, x));
+          HitRec sh;
+          // camera.cpp:101-102: the light is skipped only when this ray hits nothing
+          if (!(F.debug & 1u) && !walk<MODE, true, COUNT, false>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
+          float c = dot(to, nrm);
+          if (c < 0.0f) c = 0.0f;
+          float y = dot(to, ln);
+          if (y < 0.0f) y = 0.0f;
+          const double nn = (double)norm(to);
+          y = (float)((double)y / (nn * nn));  // std::pow(norm, 2) in double, camera.cpp:111
+          local = add(local, scale(scale(scale(lke, c), y), inv_area_f));
         }
-        const float4 *qp = reinterpret_cast<const float4 *>(S.light_tris + first + lo);
-        const float4 g0 = qp[0], g1 = qp[1], g2 = qp[2];
-        const V3 lu = mk(g0.x, g0.y, g0.z), lv = mk(g0.w, g1.x, g1.y), ln = mk(g1.z, g1.w, g2.x);
-        // Triangle::sample, object.cpp:432-442 (the point is relative to v0; v0 is not added)
-        const double s = (double)rng.real(0.0f, 1.0f, base + 3u * l + 1u);
-        const double tt = (double)rng.real(0.0f, 1.0f, base + 3u * l + 2u);
-        V3 point;
-        if (s + tt <= 1.0) point = add(scale(lu, (float)s), scale(lv, (float)tt));
-        else point = add(scale(lu, (float)(1.0 - s)), scale(lv, (float)(1.0 - tt)));
-        const V3 to = normalize(sub(point, x));
-        HitRec sh;
-        // camera.cpp:101-102: the light is skipped only when this ray hits nothing
-        if (!walk<MODE, true, COUNT>(S, x, to, stk + threadIdx.x, kBlock, sh, nb, nt)) continue;
-        float c = dot(to, nrm);
-        if (c < 0.0f) c = 0.0f;
-        float y = dot(to, ln);
-        if (y < 0.0f) y = 0.0f;
-        const double nn = (double)norm(to);
-        y = (float)((double)y / (nn * nn));  // std::pow(norm, 2) in double, camera.cpp:111
-        local = add(local, scale(scale(scale(lke, c), y), inv_area_f));
-      }
 
-      // Russian roulette, camera.cpp:118-119; the draw happens only when depth > rr_min_depth
-      bool cont = depth <= F.rr_min_depth ||
-                  (double)rng.real(0.0f, 1.0f, base + 3u * S.n_lights) < (double)F.rr_prob;
-      if (F.max_depth > 0 && depth >= F.max_depth) cont = false;
-      if (cont) local = add(local, ke);  // camera.cpp:154
-      L = add(L, mul(T, local));
-      if (cont) {
-        const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
-        const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
-        V3 w;
-        if (F.sampling == PT_SAMPLE_COSINE) {
-          w = cosine_dir(nrm, rx, ry);
-          T = divs(mul(T, kd), F.rr_prob);
-        } else {
-          w = uniform_dir(nrm, rx, ry);
-          const V3 brdf = divs(kd, F.pi_f);                                   // camera.cpp:122
-          T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+        // Russian roulette, camera.cpp:118-119; the draw happens only when depth > rr_min_depth
+        bool cont = depth <= F.rr_min_depth ||
+                    (double)rng.real(0.0f, 1.0f, base + 3u * S.n_lights) < (double)F.rr_prob;
+        if (F.max_depth > 0 && depth >= F.max_depth) cont = false;
+        if (cont) local = add(local, ke);  // camera.cpp:154
+        L = add(L, mul(T, local));
+        if (cont) {
+          const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
+          const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
+          V3 w;
+          if (F.debug & 2u) {
+            const float ph = 6.2831853f * ry, zz = 1.0f - 2.0f * rx, rr = sqrtf(fmaxf(0.0f, 1.0f - zz * zz));
+            w = mk(__cosf(ph) * rr, __sinf(ph) * rr, zz);
+            if (dot(w, nrm) < 0.0f) w = neg(w);
+            T = divs(scale(mul(T, divs(kd, F.pi_f)), fabsf(dot(nrm, w))), F.pdf_f);
+          } else if (F.sampling == PT_SAMPLE_COSINE) {
+            w = cosine_dir(nrm, rx, ry);
+            T = divs(mul(T, kd), F.rr_prob);
+          } else {
+            w = uniform_dir(nrm, rx, ry);
+            const V3 brdf = divs(kd, F.pi_f);                                   // camera.cpp:122
+            T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+          }
+          o = x;  // no offset along the normal, camera.cpp:155
+          d = w;
+          alive = true;
         }
-        o = x;  // no offset along the normal, camera.cpp:155
-        d = w;
-        alive = true;
       }
     }
+    const unsigned long long m = __ballot(alive);
+    n_hit += (uint32_t)__popcll(__ballot(did_hit));
+    if (lane == 0) chunk_mask[run + c] = m;
+    if (alive) {
+      out.ox[i] = o.x; out.oy[i] = o.y; out.oz[i] = o.z;
+      out.dx[i] = d.x; out.dy[i] = d.y; out.dz[i] = d.z;
+      out.tx[i] = T.x; out.ty[i] = T.y; out.tz[i] = T.z;
+      out.lx[i] = L.x; out.ly[i] = L.y; out.lz[i] = L.z;
+      out.id[i] = id;
+    } else if (active) {
+      Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
+    }
   }
-  // compaction of the survivors: wave ballot + prefix count, one atomic per wave
-  const unsigned long long m = __ballot(alive);
-  const unsigned long long mh = __ballot(did_hit);
-  const int lane = threadIdx.x & 63;
-  uint32_t base_out = 0;
-  if (lane == 0) {
-    if (m) base_out = atomicAdd(&cnt[0], (uint32_t)__popcll(m));
-    if (mh) atomicAdd(&cnt[1], (uint32_t)__popcll(mh));
-  }
-  base_out = __shfl(base_out, 0);
-  if (alive) {
-    const uint32_t j = base_out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    out.ox[j] = o.x; out.oy[j] = o.y; out.oz[j] = o.z;
-    out.dx[j] = d.x; out.dy[j] = d.y; out.dz[j] = d.z;
-    out.tx[j] = T.x; out.ty[j] = T.y; out.tz[j] = T.z;
-    out.lx[j] = L.x; out.ly[j] = L.y; out.lz[j] = L.z;
-    out.id[j] = id;
-  } else if (active) {
-    Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
-  }
+  if (lane == 0 && n_hit) atomicAdd(&cnt[1], n_hit);
   if (COUNT) {
     wave_add64(stats + 2, nb);
     wave_add64(stats + 3, nt);
   }
+}
+
+// Exclusive prefix sums of the survivor counts popcount(chunk_mask[c]), two levels:
+// k_scan_local scans kScanSpan chunks per workgroup and leaves each workgroup's total in
+// block_tot; k_scan_top scans those totals in place and writes the grand total to *total.
+static const int kScanBlock = 1024;
+static const int kScanPer = 4;
+static const int kScanSpan = kScanBlock * kScanPer;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_t &block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < (int)(blockDim.x >> 6) ? wave_tot[lane] : 0u;
+    uint32_t winc = w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(winc, off);
+      if (lane >= off) winc += t;
+    }
+    if (lane < (int)(blockDim.x >> 6)) wave_tot[lane] = winc - w;
+    if (lane == 63) wave_tot[64] = winc;
+  }
+  __syncthreads();
+  block_total = wave_tot[64];
+  return wave_tot[wave] + inc - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(uint32_t n_chunks, const unsigned long long *chunk_mask,
+                                                           uint32_t *chunk_base, uint32_t *block_tot) {
+  __shared__ uint32_t wave_tot[65];
+  const uint32_t first = (blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
+  uint32_t c[kScanPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    c[k] = first + k < n_chunks ? (uint32_t)__popcll(chunk_mask[first + k]) : 0u;
+    sum += c[k];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(sum, wave_tot, total);
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    if (first + k < n_chunks) chunk_base[first + k] = run;
+    run += c[k];
+  }
+  if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t n_blocks, uint32_t *block_tot, uint32_t *total) {
+  __shared__ uint32_t wave_tot[65];
+  const uint32_t v = threadIdx.x < n_blocks ? block_tot[threadIdx.x] : 0u;
+  uint32_t all;
+  const uint32_t ex = block_exclusive_scan(v, wave_tot, all);
+  if (threadIdx.x < n_blocks) block_tot[threadIdx.x] = ex;
+  if (threadIdx.x == 0) *total = all;
+}
+
+// Packs the survivors of `src` (left at their own indices by k_shade) into the front of `dst`.
+__global__ __launch_bounds__(kBlock) void k_compact(uint32_t n_chunks, const unsigned long long *chunk_mask,
+                                                    const uint32_t *chunk_base, const uint32_t *block_off, QueueDev src,
+                                                    QueueDev dst) {
+  const uint32_t chunk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (chunk >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = chunk_mask[chunk];
+  if (!((m >> lane) & 1ull)) return;
+  const uint32_t j = block_off[chunk / kScanSpan] + chunk_base[chunk] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  const uint32_t i = chunk * 64u + (uint32_t)lane;
+  dst.ox[j] = src.ox[i]; dst.oy[j] = src.oy[i]; dst.oz[j] = src.oz[i];
+  dst.dx[j] = src.dx[i]; dst.dy[j] = src.dy[i]; dst.dz[j] = src.dz[i];
+  dst.tx[j] = src.tx[i]; dst.ty[j] = src.ty[i]; dst.tz[j] = src.tz[i];
+  dst.lx[j] = src.lx[i]; dst.ly[j] = src.ly[i]; dst.lz[j] = src.lz[i];
+  dst.id[j] = src.id[i];
 }
 
 // accum[p] += sum over the batch's samples, in sample order (so the float sum does not
@@ -365,11 +539,22 @@ static int fail(int code, const std::string &msg) {
 
 struct Workspace {
   size_t cap = 0;
-  float *block = nullptr;  // 2 queues x 13 arrays + hit_t + hit_slot + 3 radiance arrays
+  float *block = nullptr;  // 2 queues x 13 arrays + 5 hit arrays + 3 radiance arrays
   QueueDev q[2];
-  float *hit_t = nullptr;
-  uint32_t *hit_slot = nullptr;
+  HitDev hit{};
   float *Lr = nullptr, *Lg = nullptr, *Lb = nullptr;
+  unsigned long long *chunk_mask = nullptr;  // one per 64 queue entries
+  uint32_t *chunk_base = nullptr;
+  uint32_t *block_tot = nullptr;             // one per kScanSpan chunks, at most kScanBlock
+};
+
+// Launch geometry of the traversal kernels for one scene.
+struct Plan {
+  int stack = 0;       // LDS stack entries per lane: 16, 32, 64 or 128
+  int block = 0;       // threads per workgroup
+  LdsPlan lds{};       // staged part of the scene
+  size_t lds_bytes = 0;
+  unsigned max_blocks = 0;  // workgroups the chip keeps resident
 };
 
 struct PtScene {
@@ -382,8 +567,9 @@ struct PtScene {
   ptl::LightTri *d_ltris = nullptr;
   uint32_t max_depth = 0, n_meshes = 0;
   uint64_t bytes = 0;
+  Plan plan;
   Workspace ws;
-  uint32_t *d_cnt = nullptr;               // 2 words per pass
+  uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, trace head, shade head
   unsigned long long *d_stats = nullptr;   // node boxes, triangle tests: closest [0,1], visibility [2,3]
   uint32_t *h_cnt = nullptr;               // pinned
   unsigned long long *h_stats = nullptr;   // pinned
@@ -393,12 +579,56 @@ struct PtScene {
   PtProfile prof{};
 };
 
+// LDS stack entries per lane for a tree of the given depth (a few fixed sizes, so that the
+// launch geometry does not change with every scene).
 static int stack_class(uint32_t depth) {
-  if (depth <= 16) return 16;
-  if (depth <= 32) return 32;
-  if (depth <= 64) return 64;
-  if (depth <= 128) return 128;
+  static const int sizes[] = {8, 12, 16, 24, 32, 48, 64, 96, 128};
+  for (int sz : sizes)
+    if (depth <= (uint32_t)sz) return sz;
   return 0;
+}
+
+// 160 KiB of LDS per CU: the per-lane stacks take STACK*4 bytes per thread, the rest
+// holds the top of the tree and, when they fit as well, all triangles.
+static int make_plan(PtScene *s) {
+  Plan &p = s->plan;
+  p.stack = stack_class(s->max_depth);
+  if (!p.stack) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  p.block = p.stack <= 32 ? 1024 : (p.stack <= 64 ? 512 : 256);
+  if (const char *e = std::getenv("PT_BLOCK")) {  // tuning knob
+    const int b = std::atoi(e);
+    if ((b == 256 || b == 512 || b == 1024) && (size_t)p.stack * b * 4 <= 128 * 1024) p.block = b;
+  }
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+  const size_t lds_cu = 160 * 1024;
+  if (const char *e = std::getenv("PT_STACK")) {  // tuning knob: never below what the tree needs
+    const int st = std::atoi(e);
+    if (st >= p.stack && st <= 128) p.stack = st;
+  }
+  const size_t stack_bytes = (size_t)p.stack * p.block * 4;
+  size_t budget = lds_cu - stack_bytes - 512;
+  if (const char *e = std::getenv("PT_LDS_BUDGET_KB")) {
+    const size_t kb = (size_t)std::atol(e) * 1024;
+    if (kb < budget) budget = kb;
+  }
+  const size_t node_bytes = (size_t)s->dev.n_nodes * sizeof(ptl::WideNode);
+  const size_t tri_bytes = (size_t)s->dev.n_tris * sizeof(ptl::TriRec);
+  if (node_bytes + tri_bytes <= budget) {
+    p.lds.n_nodes = s->dev.n_nodes;
+    p.lds.n_tris = s->dev.n_tris;
+  } else {
+    const size_t fit = budget / sizeof(ptl::WideNode);
+    p.lds.n_nodes = (uint32_t)(fit < s->dev.n_nodes ? fit : s->dev.n_nodes);
+    p.lds.n_tris = 0;
+  }
+  p.lds_bytes = (size_t)p.lds.n_nodes * sizeof(ptl::WideNode) + (size_t)p.lds.n_tris * sizeof(ptl::TriRec) + stack_bytes;
+  unsigned per_cu = (unsigned)(lds_cu / p.lds_bytes);
+  const unsigned by_threads = 2048u / (unsigned)p.block;
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu < 1) per_cu = 1;
+  p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
+  return PT_OK;
 }
 
 static void free_workspace(Workspace &w) {
@@ -410,9 +640,12 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   Workspace &w = s->ws;
   if (w.cap >= cap) return PT_OK;
   free_workspace(w);
-  const size_t arrays = 2 * 13 + 2 + 3;
+  const size_t arrays = 2 * 13 + 5 + 3;
   const size_t stride = (cap + 63) & ~(size_t)63;
-  HIP_TRY(hipMalloc(&w.block, arrays * stride * sizeof(float)));
+  const size_t n_chunks = stride / 64;
+  if ((n_chunks + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock) return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
+  const size_t extra = n_chunks * 12 + (size_t)kScanBlock * 4 + 256;
+  HIP_TRY(hipMalloc(&w.block, arrays * stride * sizeof(float) + extra));
   float *p = w.block;
   auto take = [&]() { float *r = p; p += stride; return r; };
   for (int k = 0; k < 2; ++k) {
@@ -421,72 +654,113 @@ static int ensure_workspace(PtScene *s, size_t cap) {
     q.tx = take(); q.ty = take(); q.tz = take(); q.lx = take(); q.ly = take(); q.lz = take();
     q.id = reinterpret_cast<uint32_t *>(take());
   }
-  w.hit_t = take();
-  w.hit_slot = reinterpret_cast<uint32_t *>(take());
+  w.hit.t = take(); w.hit.nx = take(); w.hit.ny = take(); w.hit.nz = take();
+  w.hit.mat = reinterpret_cast<uint32_t *>(take());
   w.Lr = take(); w.Lg = take(); w.Lb = take();
+  w.chunk_mask = reinterpret_cast<unsigned long long *>(p);
+  w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
+  w.block_tot = w.chunk_base + n_chunks;
   w.cap = cap;
   return PT_OK;
 }
 
+// Dynamic LDS above 64 KiB has to be allowed per kernel once.
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return PT_OK;
+}
+
+// Chunks of 64 items a wave claims at once: about a quarter of its share of the launch,
+// between 1 and 16.
+static uint32_t run_length(const Plan &p, size_t n) {
+  const size_t chunks = (n + 63) / 64;
+  const size_t waves = (size_t)p.max_blocks * (size_t)(p.block / 64);
+  size_t r = chunks / (waves * 4);
+  if (r < 1) r = 1;
+  if (r > 16) r = 16;
+  return (uint32_t)r;
+}
+
+static dim3 grid_for(const Plan &p, size_t n) {
+  size_t g = (n + p.block - 1) / p.block;
+  if (g > p.max_blocks) g = p.max_blocks;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+// Calls f(BLOCK) with the plan's workgroup size as an integral constant.
+template <typename F>
+static int dispatch_plan(const Plan &p, F &&f) {
+  switch (p.block) {
+    case 256: return f(std::integral_constant<int, 256>{});
+    case 512: return f(std::integral_constant<int, 512>{});
+    case 1024: return f(std::integral_constant<int, 1024>{});
+    default: return fail(PT_ERR_UNSUPPORTED, "unsupported workgroup size");
+  }
+}
+
 template <int MODE, bool COUNT>
 static int launch_trace_queue(PtScene *s, uint32_t n, const QueueDev &q, hipStream_t st) {
-  const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-  switch (stack_class(s->max_depth)) {
-    case 16: hipLaunchKernelGGL((k_trace_queue<MODE, 16, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
-    case 32: hipLaunchKernelGGL((k_trace_queue<MODE, 32, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
-    case 64: hipLaunchKernelGGL((k_trace_queue<MODE, 64, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
-    case 128: hipLaunchKernelGGL((k_trace_queue<MODE, 128, COUNT>), grid, block, 0, st, s->dev, n, q, s->ws.hit_t, s->ws.hit_slot, s->d_stats); break;
-    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
-  }
-  HIP_TRY(hipGetLastError());
-  return PT_OK;
+  return dispatch_plan(s->plan, [&](auto BL) -> int {
+    constexpr int BLOCK = decltype(BL)::value;
+    auto k = k_trace_queue<MODE, BLOCK, COUNT>;
+    int rc = allow_lds(k, s->plan.lds_bytes);
+    if (rc != PT_OK) return rc;
+    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, q,
+                       s->ws.hit, s->d_cnt + 2, s->d_stats);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+  });
 }
 
 template <int MODE, bool COUNT>
 static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, const QueueDev &in,
-                        const QueueDev &out, uint32_t *cnt, hipStream_t st) {
-  const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-  const Workspace &w = s->ws;
-  switch (stack_class(s->max_depth)) {
-    case 16: hipLaunchKernelGGL((k_shade<MODE, 16, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
-    case 32: hipLaunchKernelGGL((k_shade<MODE, 32, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
-    case 64: hipLaunchKernelGGL((k_shade<MODE, 64, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
-    case 128: hipLaunchKernelGGL((k_shade<MODE, 128, COUNT>), grid, block, 0, st, s->dev, F, depth, n, in, w.hit_t, w.hit_slot, out, cnt, w.Lr, w.Lg, w.Lb, s->d_stats); break;
-    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
-  }
-  HIP_TRY(hipGetLastError());
-  return PT_OK;
+                        const QueueDev &out, hipStream_t st) {
+  return dispatch_plan(s->plan, [&](auto BL) -> int {
+    constexpr int BLOCK = decltype(BL)::value;
+    auto k = k_shade<MODE, BLOCK, COUNT>;
+    int rc = allow_lds(k, s->plan.lds_bytes);
+    if (rc != PT_OK) return rc;
+    const Workspace &w = s->ws;
+    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n,
+                       in, w.hit, out, w.chunk_mask, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+  });
 }
 
 template <int MODE, bool COUNT>
 static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz,
                             const float *dx, const float *dy, const float *dz, float *t, int32_t *tri, float *u,
                             float *v, hipStream_t st) {
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-  switch (stack_class(s->max_depth)) {
-    case 16: hipLaunchKernelGGL((k_trace_api<MODE, 16, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
-    case 32: hipLaunchKernelGGL((k_trace_api<MODE, 32, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
-    case 64: hipLaunchKernelGGL((k_trace_api<MODE, 64, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
-    case 128: hipLaunchKernelGGL((k_trace_api<MODE, 128, COUNT>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, s->d_stats); break;
-    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
-  }
-  HIP_TRY(hipGetLastError());
-  return PT_OK;
+  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 4 * sizeof(uint32_t), st));
+  return dispatch_plan(s->plan, [&](auto BL) -> int {
+    constexpr int BLOCK = decltype(BL)::value;
+    auto k = k_trace_api<MODE, BLOCK, COUNT>;
+    int rc = allow_lds(k, s->plan.lds_bytes);
+    if (rc != PT_OK) return rc;
+    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
+                       dx, dy, dz, t, tri, u, v, s->d_cnt + 2, s->d_stats);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+  });
 }
 
 template <int MODE>
 static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
                           const float *dy, const float *dz, uint8_t *hit, hipStream_t st) {
-  const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-  switch (stack_class(s->max_depth)) {
-    case 16: hipLaunchKernelGGL((k_any_api<MODE, 16>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
-    case 32: hipLaunchKernelGGL((k_any_api<MODE, 32>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
-    case 64: hipLaunchKernelGGL((k_any_api<MODE, 64>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
-    case 128: hipLaunchKernelGGL((k_any_api<MODE, 128>), grid, block, 0, st, s->dev, n, ox, oy, oz, dx, dy, dz, hit); break;
-    default: return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
-  }
-  HIP_TRY(hipGetLastError());
-  return PT_OK;
+  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 4 * sizeof(uint32_t), st));
+  return dispatch_plan(s->plan, [&](auto BL) -> int {
+    constexpr int BLOCK = decltype(BL)::value;
+    auto k = k_any_api<MODE, BLOCK>;
+    int rc = allow_lds(k, s->plan.lds_bytes);
+    if (rc != PT_OK) return rc;
+    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
+                       dx, dy, dz, hit, s->d_cnt + 2);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+  });
 }
 
 static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const PtOptions *opt, uint32_t n_lights,
@@ -517,6 +791,7 @@ static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const Pt
   F.pdf_f = (float)(1 / (2 * M_PI) * (double)o.rr_prob);
   F.pi_f = (float)M_PI;
   F.dims_per_vertex = (3u * n_lights + 3u + 1u) & ~1u;
+  if (const char *e = std::getenv("PT_DEBUG_FLAGS")) F.debug = (uint32_t)std::atoi(e);
   return PT_OK;
 }
 
@@ -587,17 +862,17 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(up(&s->d_mats, f.mats));
   HIP_TRY(up(&s->d_lights, f.lights));
   HIP_TRY(up(&s->d_ltris, f.light_tris));
-  HIP_TRY(hipMalloc(&s->d_cnt, 2 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&s->d_cnt, 4 * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&s->d_stats, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
-  HIP_TRY(hipHostMalloc(&s->h_cnt, 2 * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&s->h_cnt, 4 * sizeof(uint32_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc(&s->h_stats, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   s->dev.nodes = s->d_nodes; s->dev.tris = s->d_tris; s->dev.mats = s->d_mats;
   s->dev.lights = s->d_lights; s->dev.light_tris = s->d_ltris;
   s->dev.n_nodes = (uint32_t)f.nodes.size(); s->dev.n_tris = (uint32_t)f.tris.size();
   s->dev.n_lights = (uint32_t)f.lights.size(); s->dev.n_mats = (uint32_t)f.mats.size();
   s->max_depth = f.max_depth; s->n_meshes = f.n_meshes;
-  return PT_OK;
+  return make_plan(s);
 }
 
 int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out) {
@@ -807,7 +1082,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
   // tail of Russian roulette, bounded by memory (about 124 bytes per path)
   uint32_t batch = o.batch_spp;
   if (batch == 0) {
-    const uint64_t target = 16ull << 20;
+    const uint64_t target = 64ull << 20;
     batch = (uint32_t)((target + F.P - 1) / F.P);
   }
   if (batch > spp_count) batch = spp_count;
@@ -837,18 +1112,25 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
       if ((rc = elapsed(0, 3, s->prof.other_ms)) != PT_OK) return rc;
     }
     c.paths += n;
-    int cur = 0;
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
-      HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 2 * sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 4 * sizeof(uint32_t), st));
       if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
-      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, n, w.q[cur], st);
-      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, n, w.q[cur], st);
+      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, n, w.q[0], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, n, w.q[0], st);
+      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, n, w.q[0], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, n, w.q[0], st);
       if (rc != PT_OK) return rc;
       if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
-      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st) : launch_shade<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st);
-      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st) : launch_shade<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], s->d_cnt, st);
+      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[0], w.q[1], st) : launch_shade<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[0], w.q[1], st);
+      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, F, depth, n, w.q[0], w.q[1], st) : launch_shade<PT_TRACE_FAST, false>(s, F, depth, n, w.q[0], w.q[1], st);
       if (rc != PT_OK) return rc;
+      {
+        const uint32_t n_chunks = (n + 63) / 64, n_sblocks = (n_chunks + kScanSpan - 1) / kScanSpan;
+        hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n_chunks, w.chunk_mask, w.chunk_base, w.block_tot);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, s->d_cnt);
+        hipLaunchKernelGGL(k_compact, dim3((n_chunks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, n_chunks,
+                           w.chunk_mask, w.chunk_base, w.block_tot, w.q[1], w.q[0]);
+        HIP_TRY(hipGetLastError());
+      }
       if (prof) HIP_TRY(hipEventRecord(s->ev[2], st));
       HIP_TRY(hipMemcpyAsync(s->h_cnt, s->d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -862,7 +1144,6 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
       c.rays_shadow += (uint64_t)s->h_cnt[1] * s->dev.n_lights;
       c.bounce_passes += 1;
       n = s->h_cnt[0];
-      cur ^= 1;
     }
     if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
     hipLaunchKernelGGL(k_resolve, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, w.Lr, w.Lg, w.Lb, accum);

@@ -24,7 +24,7 @@ enum : uint32_t {
 //   bit 31 = 1: leaf, bits 28..30 = count-1 (1..8 triangles), bits 0..27 = first triangle slot
 static const uint32_t REF_LEAF = 0x80000000u;
 static const uint32_t REF_FIRST_MASK = 0x0fffffffu;
-static const uint32_t MAX_TRI_SLOTS = 1u << 28;
+static const uint32_t MAX_TRI_SLOTS = (1u << 28) - 8u;
 
 // 64-byte node holding the boxes of both children.  As four float4:
 //   q0 = lo0.x lo0.y lo0.z hi0.x
