@@ -14,7 +14,6 @@
 
 namespace ptd {
 
-using ptl::KIND_EMPTY;
 using ptl::KIND_GROUP;
 using ptl::KIND_INTERNAL;
 using ptl::KIND_LEAF;
@@ -112,9 +111,10 @@ struct HitRec {
   uint32_t mat;   // its material id (only with WANT_N)
 };
 
-// Slack of the optional tests of the fast mode (a relative 2^-12 plus a small
-// absolute term).  The reference compares nothing against a running best, so any
-// pruning must never drop a triangle whose computed t could still win.
+// Slack of the pruning of the fast mode (a relative 2^-12 plus a small absolute term).
+// The reference compares nothing against a running best, so pruning must never drop a
+// triangle whose computed t could still win.  (The boxes of leaves and groups, which the
+// reference never tests, are widened by the flattener for the same reason.)
 #define PT_SLACK_REL 2.44140625e-4f
 #define PT_SLACK_ABS 2.0e-5f
 
@@ -224,7 +224,8 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
       }
       if (COUNT) n_boxes += 2;
       // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-      float tn0 = 1e-5f, tf0 = __builtin_inff(), tn1 = 1e-5f, tf1 = __builtin_inff();
+      const float far = (MODE == PT_TRACE_FAST && !ANY) ? cull : __builtin_inff();
+      float tn0 = 1e-5f, tf0 = far, tn1 = 1e-5f, tf1 = far;
       {
         const float a0 = ((sx ? q0.w : q0.x) - o.x) * ix, b0 = ((sx ? q0.x : q0.w) - o.x) * ix;
         const float a1 = ((sx ? q2.y : q1.z) - o.x) * ix, b1 = ((sx ? q1.z : q2.y) - o.x) * ix;
@@ -243,20 +244,16 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
         tn0 = fmaxf(tn0, a0); tf0 = fminf(tf0, b0);
         tn1 = fmaxf(tn1, a1); tf1 = fminf(tf1, b1);
       }
-      const uint32_t k0 = q3.z, k1 = q3.w;
       bool p0, p1;
       if (MODE == PT_TRACE_EXACT) {
-        p0 = (k0 == KIND_INTERNAL) ? (tf0 >= tn0) : (k0 != KIND_EMPTY);
-        p1 = (k1 == KIND_INTERNAL) ? (tf1 >= tn1) : (k1 != KIND_EMPTY);
+        // only an internal node of the reference tree is box-tested there (object.cpp:277)
+        p0 = (q3.z == KIND_INTERNAL) ? (tf0 >= tn0) : true;
+        p1 = (q3.w == KIND_INTERNAL) ? (tf1 >= tn1) : true;
       } else {
-        const bool soft0 = tf0 + ((fabsf(tf0) + tn0) * PT_SLACK_REL + PT_SLACK_ABS) >= tn0;
-        const bool soft1 = tf1 + ((fabsf(tf1) + tn1) * PT_SLACK_REL + PT_SLACK_ABS) >= tn1;
-        p0 = (k0 == KIND_INTERNAL) ? (tf0 >= tn0) : (k0 != KIND_EMPTY && soft0);
-        p1 = (k1 == KIND_INTERNAL) ? (tf1 >= tn1) : (k1 != KIND_EMPTY && soft1);
-        if (!ANY) {
-          p0 = p0 && !(tn0 > cull);
-          p1 = p1 && !(tn1 > cull);
-        }
+        // leaf and group boxes were widened by the flattener, and tf started at the cull
+        // distance, so one comparison covers the box test and the pruning
+        p0 = tf0 >= tn0;
+        p1 = tf1 >= tn1;
       }
       if (p0 && p1) {
         const bool swap = (MODE == PT_TRACE_FAST && !ANY) ? (tn1 < tn0) : false;

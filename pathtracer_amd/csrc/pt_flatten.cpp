@@ -49,7 +49,8 @@ struct Flattener {
     failed = true;
     Entry e;
     memset(&e, 0, sizeof(e));
-    e.kind = KIND_EMPTY;
+    e.ref = REF_LEAF;
+    e.kind = KIND_LEAF;
     return e;
   }
 
@@ -72,16 +73,41 @@ struct Flattener {
     return (uint32_t)nodes.size() - 1;
   }
 
-  static Entry empty_entry() {
+  // A child slot that leads nowhere: a leaf holding one degenerate triangle (all zeros: its
+  // determinant is 0, so Triangle::intersect's first test rejects it for every ray) behind a
+  // box no ray enters.  This way the walk needs no "empty" case.
+  Entry empty_entry() {
     Entry e;
     for (int k = 0; k < 3; ++k) {
       e.lo[k] = INFINITY;
       e.hi[k] = -INFINITY;
     }
-    e.ref = 0;
-    e.kind = KIND_EMPTY;
+    TriRec r;
+    memset(&r, 0, sizeof(r));
+    r.tri_id = 0xffffffffu;
+    out.tris.push_back(r);
+    e.ref = REF_LEAF | next_slot;
+    ++next_slot;
+    e.kind = KIND_LEAF;
     e.depth = 0;
     return e;
+  }
+
+  // Boxes of leaves and groups are never tested by the reference; the fast traversal mode
+  // uses them to skip work, so they are widened by 2^-11 of the largest coordinate plus a
+  // small absolute margin: a triangle whose computed hit lies a few rounding errors outside
+  // its exact box must not be lost.
+  static void widen(Entry &e) {
+    float m = 0;
+    for (int k = 0; k < 3; ++k) {
+      if (std::isfinite(e.lo[k])) m = std::max(m, std::fabs(e.lo[k]));
+      if (std::isfinite(e.hi[k])) m = std::max(m, std::fabs(e.hi[k]));
+    }
+    const float d = m * (1.0f / 2048.0f) + 2.0e-5f;
+    for (int k = 0; k < 3; ++k) {
+      e.lo[k] -= d;
+      e.hi[k] += d;
+    }
   }
 
   // Balanced grouping nodes over es[lo, hi).
@@ -97,7 +123,7 @@ struct Flattener {
     g.ref = make_node(a, b);
     g.kind = KIND_GROUP;
     g.depth = 1 + std::max(a.depth, b.depth);
-    return g;
+    return g;  // union of already widened boxes
   }
 
   void put_triangle(uint32_t mesh, uint32_t local) {
@@ -144,6 +170,7 @@ struct Flattener {
         c.ref = REF_LEAF | ((cnt - 1) << 28) | s;
         c.kind = KIND_LEAF;
         c.depth = 0;
+        widen(c);
         chunks.push_back(c);
       }
       return group(chunks, 0, chunks.size());
@@ -198,8 +225,8 @@ struct Flattener {
     auto kids = [&](uint32_t i, uint32_t k[2]) {
       int c = 0;
       const WideNode &w = nodes[i];
-      if (w.kind0 != KIND_EMPTY && !(w.ref0 & REF_LEAF)) k[c++] = w.ref0;
-      if (w.kind1 != KIND_EMPTY && !(w.ref1 & REF_LEAF)) k[c++] = w.ref1;
+      if (!(w.ref0 & REF_LEAF)) k[c++] = w.ref0;
+      if (!(w.ref1 & REF_LEAF)) k[c++] = w.ref1;
       return c;
     };
     while (!q.empty() && order.size() < kTopNodes) {
@@ -227,8 +254,8 @@ struct Flattener {
     out.nodes.resize(order.size());
     for (uint32_t j = 0; j < order.size(); ++j) {
       WideNode w = nodes[order[j]];
-      if (w.kind0 != KIND_EMPTY && !(w.ref0 & REF_LEAF)) w.ref0 = newidx[w.ref0];
-      if (w.kind1 != KIND_EMPTY && !(w.ref1 & REF_LEAF)) w.ref1 = newidx[w.ref1];
+      if (!(w.ref0 & REF_LEAF)) w.ref0 = newidx[w.ref0];
+      if (!(w.ref1 & REF_LEAF)) w.ref1 = newidx[w.ref1];
       out.nodes[j] = w;
     }
   }
@@ -305,7 +332,7 @@ struct Flattener {
     mesh_seen.assign(d.n_meshes, 0);
     tlas_seen.assign(d.n_tlas_nodes, 0);
     blas_seen.assign(d.blas_node_offset[d.n_meshes], 0);
-    out.tris.reserve(d.n_tris);
+    out.tris.reserve((size_t)d.n_tris + 1);
     Entry root = tlas_node(0, 0);
     if (failed) return PT_ERR_INVALID;
     if (next_slot != d.n_tris) {

@@ -907,7 +907,7 @@ int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out) {
 
 int pt_scene_info(const PtScene *s, PtSceneInfo *info) {
   if (!s || !info) return fail(PT_ERR_INVALID, "null argument");
-  info->n_meshes = s->n_meshes; info->n_tris = s->dev.n_tris; info->n_lights = s->dev.n_lights;
+  info->n_meshes = s->n_meshes; info->n_tris = s->dev.n_tris - 1;  // without the degenerate filler info->n_lights = s->dev.n_lights;
   info->n_wide_nodes = s->dev.n_nodes; info->max_depth = s->max_depth; info->device = (uint32_t)s->device;
   info->device_bytes = s->bytes;
   return PT_OK;

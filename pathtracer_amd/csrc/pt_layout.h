@@ -15,8 +15,7 @@ enum : uint32_t {
   KIND_INTERNAL = 0,  // an internal node of the reference tree: its own box test decides (object.cpp:277)
   KIND_GROUP = 1,     // grouping node that does not exist in the reference (several meshes of one
                       // top-level leaf, or the super-root): the reference visits everything below it
-  KIND_LEAF = 2,      // triangle leaf: the reference never box-tests a leaf (object.cpp:266-275)
-  KIND_EMPTY = 3
+  KIND_LEAF = 2       // triangle leaf: the reference never box-tests a leaf (object.cpp:266-275)
 };
 
 // Encoding of a traversal-stack entry / child reference.
