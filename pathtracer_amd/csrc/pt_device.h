@@ -101,6 +101,7 @@ struct SceneDev {
   const ptl::LightRec *lights;
   const ptl::LightTri *light_tris;
   uint32_t n_nodes, n_tris, n_lights, n_mats;
+  float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
 };
 
 struct HitRec {
@@ -189,12 +190,24 @@ struct LdsScene {
 template <int MODE, bool ANY, bool COUNT, bool WANT_N = false>
 __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o, V3 d, uint32_t stk, uint32_t stride,
                                      HitRec &best, uint32_t &n_boxes, uint32_t &n_tris) {
-  const float qnan = __builtin_nanf("");
-  // 1/d per axis as AABB::intersect forms it (object.cpp:183); an axis with d == 0 is
-  // skipped there, which a NaN reciprocal reproduces: NaN never updates tmin/tmax.
-  const float ix = d.x != 0.0f ? 1.0f / d.x : qnan;
-  const float iy = d.y != 0.0f ? 1.0f / d.y : qnan;
-  const float iz = d.z != 0.0f ? 1.0f / d.z : qnan;
+  // 1/d per axis as AABB::intersect forms it (object.cpp:183).  An axis with d == 0 is
+  // skipped there without checking that the origin lies inside the slab; a NaN reciprocal
+  // reproduces that (NaN never updates tmin/tmax).  Such a ray then passes every box on that
+  // axis and walks a large part of the tree for nothing, so the fast mode uses +INF instead:
+  // (plane - o) * INF is -INF/+INF on the two sides of the origin and NaN on it, i.e. the
+  // slab restricts nothing when the origin is inside or on it and rejects the box otherwise.
+  // The box is taken S.margin wider for this check (separate origins for the two planes of
+  // the slab): node boxes touch triangle edges, and an edge a rounding error away from the
+  // ray's plane can still be hit by the reference's triangle test.
+  const float skip = (MODE == PT_TRACE_FAST) ? __builtin_inff() : __builtin_nanf("");
+  const float ix = d.x != 0.0f ? 1.0f / d.x : skip;
+  const float iy = d.y != 0.0f ? 1.0f / d.y : skip;
+  const float iz = d.z != 0.0f ? 1.0f / d.z : skip;
+  const float mx = (MODE == PT_TRACE_FAST && d.x == 0.0f) ? S.margin : 0.0f;
+  const float my = (MODE == PT_TRACE_FAST && d.y == 0.0f) ? S.margin : 0.0f;
+  const float mz = (MODE == PT_TRACE_FAST && d.z == 0.0f) ? S.margin : 0.0f;
+  const V3 on = mk(o.x + mx, o.y + my, o.z + mz);  // origin for the entry planes
+  const V3 of = mk(o.x - mx, o.y - my, o.z - mz);  // origin for the exit planes
   const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
   best.t = __builtin_inff();
   best.slot = 0xffffffffu;
@@ -227,20 +240,20 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
       const float far = (MODE == PT_TRACE_FAST && !ANY) ? cull : __builtin_inff();
       float tn0 = 1e-5f, tf0 = far, tn1 = 1e-5f, tf1 = far;
       {
-        const float a0 = ((sx ? q0.w : q0.x) - o.x) * ix, b0 = ((sx ? q0.x : q0.w) - o.x) * ix;
-        const float a1 = ((sx ? q2.y : q1.z) - o.x) * ix, b1 = ((sx ? q1.z : q2.y) - o.x) * ix;
+        const float a0 = ((sx ? q0.w : q0.x) - on.x) * ix, b0 = ((sx ? q0.x : q0.w) - of.x) * ix;
+        const float a1 = ((sx ? q2.y : q1.z) - on.x) * ix, b1 = ((sx ? q1.z : q2.y) - of.x) * ix;
         tn0 = fmaxf(tn0, a0); tf0 = fminf(tf0, b0);
         tn1 = fmaxf(tn1, a1); tf1 = fminf(tf1, b1);
       }
       {
-        const float a0 = ((sy ? q1.x : q0.y) - o.y) * iy, b0 = ((sy ? q0.y : q1.x) - o.y) * iy;
-        const float a1 = ((sy ? q2.z : q1.w) - o.y) * iy, b1 = ((sy ? q1.w : q2.z) - o.y) * iy;
+        const float a0 = ((sy ? q1.x : q0.y) - on.y) * iy, b0 = ((sy ? q0.y : q1.x) - of.y) * iy;
+        const float a1 = ((sy ? q2.z : q1.w) - on.y) * iy, b1 = ((sy ? q1.w : q2.z) - of.y) * iy;
         tn0 = fmaxf(tn0, a0); tf0 = fminf(tf0, b0);
         tn1 = fmaxf(tn1, a1); tf1 = fminf(tf1, b1);
       }
       {
-        const float a0 = ((sz ? q1.y : q0.z) - o.z) * iz, b0 = ((sz ? q0.z : q1.y) - o.z) * iz;
-        const float a1 = ((sz ? q2.w : q2.x) - o.z) * iz, b1 = ((sz ? q2.x : q2.w) - o.z) * iz;
+        const float a0 = ((sz ? q1.y : q0.z) - on.z) * iz, b0 = ((sz ? q0.z : q1.y) - of.z) * iz;
+        const float a1 = ((sz ? q2.w : q2.x) - on.z) * iz, b1 = ((sz ? q2.x : q2.w) - of.z) * iz;
         tn0 = fmaxf(tn0, a0); tf0 = fminf(tf0, b0);
         tn1 = fmaxf(tn1, a1); tf1 = fminf(tf1, b1);
       }

@@ -135,6 +135,8 @@ struct Flattener {
       r.e1[k] = p[3 + k] - p[k];
       r.e2[k] = p[6 + k] - p[k];
     }
+    for (int k = 0; k < 9; ++k)
+      if (std::isfinite(p[k])) out.max_abs_coord = std::max(out.max_abs_coord, std::fabs(p[k]));
     r.tri_id = gid;
     r.mat_id = d.mesh_material[mesh];
     r.mesh_id = mesh;

@@ -18,6 +18,7 @@ struct FlatScene {
   std::vector<LightTri> light_tris;
   uint32_t max_depth = 0;            // stack entries the deepest descent needs
   uint32_t n_meshes = 0;
+  float max_abs_coord = 0;           // largest |coordinate| of any vertex
 };
 
 // Returns PT_OK or a negative PtStatus with `err` filled in.

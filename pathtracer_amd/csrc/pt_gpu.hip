@@ -871,6 +871,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.lights = s->d_lights; s->dev.light_tris = s->d_ltris;
   s->dev.n_nodes = (uint32_t)f.nodes.size(); s->dev.n_tris = (uint32_t)f.tris.size();
   s->dev.n_lights = (uint32_t)f.lights.size(); s->dev.n_mats = (uint32_t)f.mats.size();
+  s->dev.margin = f.max_abs_coord * (1.0f / 2048.0f) + 2.0e-5f;
   s->max_depth = f.max_depth; s->n_meshes = f.n_meshes;
   return make_plan(s);
 }
@@ -907,7 +908,9 @@ int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out) {
 
 int pt_scene_info(const PtScene *s, PtSceneInfo *info) {
   if (!s || !info) return fail(PT_ERR_INVALID, "null argument");
-  info->n_meshes = s->n_meshes; info->n_tris = s->dev.n_tris - 1;  // without the degenerate filler info->n_lights = s->dev.n_lights;
+  info->n_meshes = s->n_meshes;
+  info->n_tris = s->dev.n_tris - 1;  // without the degenerate filler
+  info->n_lights = s->dev.n_lights;
   info->n_wide_nodes = s->dev.n_nodes; info->max_depth = s->max_depth; info->device = (uint32_t)s->device;
   info->device_bytes = s->bytes;
   return PT_OK;
