@@ -191,6 +191,15 @@ class DeviceScene:
             "mesh_material": np.ascontiguousarray(arrays["mesh_material"], np.uint32),
             "materials": np.ascontiguousarray(arrays["materials"], MAT_DTYPE),
         }
+        nm, nt = len(a["mesh_material"]), len(a["blas_order"])
+        if nm == 0 or nt == 0:
+            raise ValueError("empty scene")
+        if len(a["tlas_order"]) != nm or len(a["blas_node_offset"]) != nm + 1 or len(a["tri_offset"]) != nm + 1:
+            raise ValueError("per-mesh arrays disagree in length")
+        if a["tri_verts"].size != nt * 9 or int(a["tri_offset"][-1]) != nt:
+            raise ValueError("triangle arrays disagree in length")
+        if int(a["blas_node_offset"][-1]) != len(a["blas_nodes"]):
+            raise ValueError("blas_node_offset does not end at len(blas_nodes)")
         d = PtSceneDesc()
         d.n_meshes = len(a["mesh_material"])
         d.n_tris = len(a["blas_order"])

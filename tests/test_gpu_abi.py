@@ -1,0 +1,171 @@
+"""GPU tests of the boundary itself: error behaviour of the C ABI, the host-side Scene/Camera mirror
+driving it, the device-pointer entry points and the headless driver."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import util
+from oracle import pt_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from pathtracer_amd import api
+    assert api.device_count() >= 1
+    return api
+
+
+def test_malformed_descriptions_are_rejected(api):
+    good = util.world("box").export()
+
+    def broken(**changes):
+        e = {k: v.copy() for k, v in good.items()}
+        for k, f in changes.items():
+            f(e[k])
+        return e
+
+    def set_(idx, field, val):
+        def f(a):
+            a[field][idx] = val
+        return f
+
+    def assign(idx, val):
+        def f(a):
+            a[idx] = val
+        return f
+
+    cases = [
+        broken(blas_nodes=set_(0, "index_or_first", 10 ** 6)),     # child index out of range
+        broken(blas_order=assign(0, 10 ** 6)),                      # triangle id out of range
+        broken(blas_order=assign(1, int(good["blas_order"][0]))),   # a triangle twice, another never
+        broken(tlas_order=assign(0, 77)),                           # mesh id out of range
+        broken(mesh_material=assign(0, 99)),                        # material out of range
+        broken(blas_nodes=set_(1, "index_or_first", 1)),            # node referenced twice / cycle
+    ]
+    for e in cases:
+        with pytest.raises(api.PtError) as ei:
+            api.DeviceScene(e)
+        assert ei.value.code == -1 and str(ei.value)
+    with pytest.raises(api.PtError):
+        api.DeviceScene(good, device=99)
+
+
+def test_null_and_bad_arguments(api):
+    L = api.lib()
+    ds = api.DeviceScene(util.world("box").export())
+    assert L.pt_scene_info(None, None) == -1
+    assert L.pt_trace_closest(ds.handle, 4, None, None, None, None, None, None, None, None, None, None, 0) == -1
+    assert b"null" in L.pt_last_error()
+    o, d = util.random_rays(16, 0)
+    with pytest.raises(api.PtError):
+        ds.trace_closest(o, d, mode=7)
+    cam = api.make_camera()
+    with pytest.raises(api.PtError):
+        ds.render(cam, 0, 10, 1, accum=np.zeros((10, 0, 3), np.float32))
+    with pytest.raises(api.PtError):
+        ds.render(api.make_camera(aperture=0.1, focus=0.0), 8, 8, 1)
+    with pytest.raises(api.PtError):
+        ds.render(cam, 8, 8, 1, opt=api.make_options(rr_prob=0.0))
+    r = ds.trace_closest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert len(r["t"]) == 0
+    acc, cnt = ds.render(cam, 8, 8, 0)
+    assert acc.sum() == 0 and cnt.paths == 0
+    ds.close()
+
+
+def test_host_scene_renders_like_the_abi(api):
+    from pathtracer_amd import host, scenes
+    meshes, mats = scenes.box_room(10)
+    hs = host.Scene.from_meshes(meshes, mats)
+    ds = hs.device_scene(0)
+    cam = api.make_camera(vw=16, vh=9)
+    W, H, spp = 80, 45, 5
+    calls = []
+    pixels, cnt = hs.render(cam, W, H, spp, seed=3, callback=lambda: calls.append(1), every=1)
+    assert len(calls) == spp                        # cb() after every pass, camera.cpp:196-197
+    sums, c2 = ds.render(cam, W, H, spp, seed=3)
+    np.testing.assert_allclose(pixels, sums / spp * 255, rtol=1e-6, atol=1e-5)
+    assert cnt.paths == c2.paths and cnt.rays_closest == c2.rays_closest
+    # and like the oracle's Camera::pixels
+    ref, _ = O.World.from_meshes(meshes, mats).render(O.default_camera(vw=16, vh=9), W, H, spp, seed=3,
+                                                       running_mean=True, form=1)
+    close = np.isclose(pixels, ref, rtol=1e-5, atol=1e-3).all(-1).mean()
+    assert close >= 0.998
+
+
+def test_device_pointer_entry_points(api):
+    import torch
+    ds = api.DeviceScene(util.world("atrium_small").export())
+    o, d = util.random_rays(5000, 4)
+    dev = torch.device("cuda", 0)
+    cols = [torch.from_numpy(np.ascontiguousarray(a[:, i])).to(dev) for a in (o, d) for i in range(3)]
+    t = torch.empty(len(o), dtype=torch.float32, device=dev)
+    tri = torch.empty(len(o), dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ds.trace_closest_dev(len(o), [c.data_ptr() for c in cols], [t.data_ptr(), tri.data_ptr(), 0, 0],
+                             mode=api.PT_TRACE_EXACT, stream=s.cuda_stream)
+    s.synchronize()
+    ref = ds.trace_closest(o, d, api.PT_TRACE_EXACT)
+    assert (t.cpu().numpy().view(np.uint32) == util.bits(ref["t"])).all()
+    assert (tri.cpu().numpy() == ref["tri"]).all()
+    cam = api.make_camera(vw=16, vh=9)
+    acc = torch.zeros(40 * 24 * 3, dtype=torch.float32, device=dev)
+    ds.render_dev(cam, 40, 24, 3, acc.data_ptr(), seed=2, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host_acc, _ = ds.render(cam, 40, 24, 3, seed=2)
+    assert (acc.cpu().numpy().view(np.uint32) == util.bits(host_acc.reshape(-1))).all()
+    ds.close()
+
+
+def test_counters_and_profile(api):
+    ds = api.DeviceScene(util.world("box").export())
+    cam = api.make_camera(vw=16, vh=9)
+    ds.count_stats(True)
+    ds.profile(True)
+    _, c = ds.render(cam, 64, 36, 4, seed=1)
+    p = ds.read_profile()
+    assert c.node_boxes > c.rays_closest and c.tri_tests > 0 and c.shadow_node_boxes > 0
+    assert p["trace_launches"] == c.bounce_passes and p["trace_ms"] > 0 and p["shade_ms"] > 0
+    ds.count_stats(False)
+    ds.profile(False)
+    _, c2 = ds.render(cam, 64, 36, 4, seed=1)
+    assert c2.node_boxes == 0 and (c2.rays_closest, c2.rays_shadow) == (c.rays_closest, c.rays_shadow)
+    # the counting kernels and the plain ones render the same image
+    a, _ = ds.render(cam, 64, 36, 4, seed=1)
+    ds.count_stats(True)
+    b, _ = ds.render(cam, 64, 36, 4, seed=1)
+    assert (util.bits(a) == util.bits(b)).all()
+    ds.close()
+
+
+def test_exact_and_fast_agree_on_a_full_render(api):
+    """Fast traversal only skips work that cannot change the answer: on a full multi-bounce render
+    (millions of rays that start on surfaces) the two modes may differ on the odd ill-conditioned
+    grazing ray; the image must agree on all but a vanishing fraction of pixels."""
+    ds = api.DeviceScene(util.world("atrium_small").export())
+    cam = api.make_camera(vw=16, vh=9)
+    a, ca = ds.render(cam, 160, 90, 8, seed=6, opt=api.make_options(trace_mode=api.PT_TRACE_EXACT))
+    b, cb = ds.render(cam, 160, 90, 8, seed=6, opt=api.make_options(trace_mode=api.PT_TRACE_FAST))
+    same = (util.bits(a) == util.bits(b)).all(-1).mean()
+    assert same >= 0.999, same
+    ds.close()
+
+
+def test_headless_driver_renders_plane_obj(tmp_path):
+    exe = os.path.join(ROOT, "pathtracer_amd", "lib", "ptrender")
+    out = str(tmp_path / "plane.ppm")
+    r = subprocess.run([exe, os.path.join(HERE, "golden", "plane.obj"), "-o", out, "--spp", "16"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "done" in r.stdout                       # camera.cpp:199
+    lines = open(out).read().split("\n")
+    assert lines[:3] == ["P3", "256 256", "255"]    # the reference's fixed size and spp (main.cpp:41-42)
+    assert set(lines[3:3 + 256 * 256]) == {"0 0 0"}  # no emitter, black background

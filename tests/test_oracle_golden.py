@@ -1,0 +1,133 @@
+"""CPU tests of the oracle: the reference's known answers (tests/golden/plane_kat.json, recorded
+from a run of the reference itself), the generator's published known answers, and the
+internal consistency of the oracle's own variants."""
+import json
+import os
+
+import numpy as np
+
+from tests import util
+from oracle import pt_oracle as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "plane_kat.json")))
+
+
+def test_plane_known_answer_rays():
+    w = util.world("plane")
+    assert (w.n_meshes, w.n_tris, w.n_lights) == (1, 2, 0)
+    o = np.array([k["o"] for k in GOLD["castray"]], np.float32)
+    d = np.array([k["d"] for k in GOLD["castray"]], np.float32)
+    r = w.castray(o, d)
+    for i, k in enumerate(GOLD["castray"]):
+        if "t_bits" in k:
+            assert int(util.bits(r["t"])[i]) == int(k["t_bits"], 16), (i, k)
+        miss = k.get("t_bits") == "0x7f800000"
+        assert (r["tri"][i] == -1) == miss
+        if "tri" in k:
+            assert r["tri"][i] == k["tri"]
+        if "bary" in k:
+            got = [r["u"][i], r["v"][i], np.float32(1) - r["u"][i] - r["v"][i]]
+            np.testing.assert_allclose(got, k["bary"], rtol=2e-6, atol=1e-9)
+
+
+def test_point_towards_known_answers():
+    d = O.camera_rays(O.default_camera(), 256, 256)
+    for key, want in GOLD["point_towards_default_camera_256"].items():
+        px, py = map(int, key.split(","))
+        np.testing.assert_allclose(d[py, px], want, rtol=1e-6, atol=1e-7)
+
+
+def test_plane_renders_black_and_counts_rays():
+    w = util.world("plane")
+    for form in (0, 1):
+        img, c = w.render(O.default_camera(), 256, 256, 16, running_mean=True, form=form)
+        assert float(np.abs(img).sum()) == GOLD["plane_render_256x256_16spp_sum"]
+        assert c.paths == 256 * 256 * 16 and c.rays_shadow == 0
+        assert c.rays_closest == c.paths  # the camera sits in the plane: no primary ray hits it (t < 1e-6)
+
+
+def test_plane_path_lengths():
+    """With no emitter and a black background every path still bounces (camera.cpp:118-156): closest-hit
+    queries exceed the path count exactly by the number of continued bounces that hit the plane again,
+    which is 0 for a single plane seen from one side."""
+    w = util.world("plane")
+    _, c = w.render(O.default_camera(origin=(0, 1, 0), euler=(0.5, 0, 0)), 64, 64, 4)
+    assert c.rays_closest >= c.paths
+
+
+def test_bvh_depth_statistic_of_the_probe_scene():
+    """The survey's probe on its 1 002-triangle room reported HitData::hits (object.cpp:203,281-282)
+    of mean 5.2, max 7 over 256x256 primary rays; the generator here follows that scene's description."""
+    w = util.world("box")
+    o, d = util.primary_rays(O.default_camera(), 256, 256)
+    r = w.castray(o, d, want_hits=True)
+    hits = r["hits"][r["tri"] >= 0]
+    mean, mx = GOLD["box_1002_tris_hits_mean_max"]
+    assert abs(hits.mean() - mean) < 0.06 and r["hits"].max() == mx
+
+
+def test_philox_known_answers():
+    for k in GOLD["philox4x32_10"]:
+        out = O.philox([int(x, 16) for x in k["ctr"]], [int(x, 16) for x in k["key"]])
+        assert [int(x) for x in out] == [int(x, 16) for x in k["out"]]
+
+
+def test_recursive_and_iterative_estimators_agree():
+    """camera.cpp:63-159 unwinds a recursion; the GPU carries a throughput forward.  Same samples,
+    different association of the float products: agreement to a few ulps per bounce."""
+    w = util.world("box")
+    cam = O.default_camera(vw=16, vh=9)
+    a, ca = w.render(cam, 96, 54, 4, seed=2, form=0)
+    b, cb = w.render(cam, 96, 54, 4, seed=2, form=1)
+    assert (ca.rays_closest, ca.rays_shadow) == (cb.rays_closest, cb.rays_shadow)
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7)
+
+
+def test_reference_generator_and_counter_generator_agree_statistically():
+    """mt19937 (math.cpp:13-18) against the counter-based generator at 64 spp: the image means differ by
+    less than 3 % (two mt19937 runs with different seeds differ by about 1 %)."""
+    w = util.world("box")
+    cam = O.default_camera(vw=16, vh=9)
+    a, _ = w.render(cam, 64, 36, 64, seed=1, rng=1, form=0)
+    b, _ = w.render(cam, 64, 36, 64, seed=1, rng=0, form=0)
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert abs(a.mean() - b.mean()) <= 0.03 * a.mean()
+
+
+def test_running_mean_equals_sum_over_spp():
+    """Camera::pixels is a running mean of radiance*255 (camera.cpp:188-190); the sums the ABI returns
+    resolve to the same image up to float rounding."""
+    w = util.world("box")
+    cam = O.default_camera(vw=16, vh=9)
+    px, _ = w.render(cam, 48, 27, 8, seed=4, form=0, running_mean=True)
+    sm, _ = w.render(cam, 48, 27, 8, seed=4, form=0)
+    np.testing.assert_allclose(px, sm / 8 * 255, rtol=1e-5, atol=1e-4)
+
+
+def test_horizontal_emitter_goes_non_finite():
+    """Triangle::area is the XY projection (object.cpp:395-404): a horizontal emitter has area 0 and the
+    reference's 1/area (camera.cpp:114) makes lit pixels non-finite.  The oracle reproduces that."""
+    v = np.array([[-1, 1.9, 2], [1, 1.9, 2], [1, 1.9, 4], [-1, 1.9, 4]], np.float32)
+    t = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    from pathtracer_amd import scenes
+    meshes, mats = scenes.box_room(4)
+    meshes[-1] = (v, t, 3)
+    w = O.World.from_meshes(meshes, mats)
+    img, _ = w.render(O.default_camera(vw=16, vh=9), 32, 18, 2)
+    assert not np.isfinite(img).all()
+
+
+def test_tree_invariants():
+    for name in ("box", "atrium_small", "blob_small", "terrain_small"):
+        e = util.world(name).export()
+        off, toff = e["blas_node_offset"], e["tri_offset"]
+        for m in range(len(off) - 1):
+            nodes = e["blas_nodes"][off[m]:off[m + 1]]
+            order = e["blas_order"][toff[m]:toff[m + 1]]
+            assert sorted(order) == list(range(len(order)))
+            leaves = nodes[nodes["count"] > 0]
+            assert leaves["count"].max() <= 8 and leaves["count"].sum() == len(order)
+            internal = nodes[nodes["count"] == 0]
+            # children are pushed as a pair right after all earlier nodes: indices are odd
+            assert (internal["index_or_first"] % 2 == 1).all()
+        assert sorted(e["tlas_order"]) == list(range(len(e["tlas_order"])))

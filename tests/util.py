@@ -88,3 +88,10 @@ def lattice_rays(k=41):
     o2[:, 2] = 1.0
     d2 = np.tile(np.array([0, 0, 1], np.float32), (len(tgt), 1))
     return np.concatenate([o, o2]), np.concatenate([d, d2])
+
+
+def GOLD_PHILOX():
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "plane_kat.json")))
+    return [([int(x, 16) for x in k["ctr"]], [int(x, 16) for x in k["key"]], [int(x, 16) for x in k["out"]])
+            for k in g["philox4x32_10"]]
