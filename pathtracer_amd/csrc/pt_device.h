@@ -174,7 +174,22 @@ struct LdsScene {
   uint32_t tri_base;   // offset of piece 0 of triangle 0
   uint32_t n_nodes;
   uint32_t n_tris;
+  // Traversal stack: the first stack_lds entries of a lane live in LDS; a tree deeper than
+  // that spills the rest to this lane's column of a global array (rarely reached: the stack
+  // only holds the far child of nodes where both children were hit).
+  uint32_t stack_lds;
+  uint32_t *spill;        // this lane's first spill entry
+  uint32_t spill_stride;  // distance between a lane's consecutive spill entries, in words
 };
+
+__device__ __forceinline__ void push_ref(const LdsScene &C, uint32_t stk, uint32_t stride, int sp, uint32_t v) {
+  if ((uint32_t)sp < C.stack_lds) stack_put(stk + (uint32_t)sp * stride, v);
+  else C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride] = v;
+}
+__device__ __forceinline__ uint32_t pop_ref(const LdsScene &C, uint32_t stk, uint32_t stride, int sp) {
+  if ((uint32_t)sp < C.stack_lds) return stack_get(stk + (uint32_t)sp * stride);
+  return C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride];
+}
 
 // Walks the tree for one ray.  MODE: PT_TRACE_EXACT reaches exactly the leaves the
 // reference reaches; PT_TRACE_FAST additionally skips leaves and groups whose box
@@ -270,7 +285,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
       }
       if (p0 && p1) {
         const bool swap = (MODE == PT_TRACE_FAST && !ANY) ? (tn1 < tn0) : false;
-        stack_put(stk + (uint32_t)sp * stride, swap ? q3.x : q3.y);
+        push_ref(C, stk, stride, sp, swap ? q3.x : q3.y);
         ++sp;
         cur = swap ? q3.y : q3.x;
         continue;
@@ -311,7 +326,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
     }
     if (sp == 0) break;
     --sp;
-    cur = stack_get(stk + (uint32_t)sp * stride);
+    cur = pop_ref(C, stk, stride, sp);
   }
   return best.slot != 0xffffffffu;
 }

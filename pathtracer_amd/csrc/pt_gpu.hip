@@ -65,8 +65,10 @@ struct FrameDev {
 // What a traversal kernel keeps in LDS (see LdsScene) and how many words of the
 // per-launch counter block it uses as its work-queue head.
 struct LdsPlan {
-  uint32_t n_nodes;  // top nodes staged in LDS
-  uint32_t n_tris;   // 0, or all triangles
+  uint32_t n_nodes;    // top nodes staged in LDS
+  uint32_t n_tris;     // 0, or all triangles
+  uint32_t stack_lds;  // stack entries per lane kept in LDS
+  uint32_t *spill;     // global spill area for deeper stacks (null when none is needed)
 };
 
 __device__ __forceinline__ V3 rotate9(const double *c, V3 p) {
@@ -156,6 +158,9 @@ __device__ __forceinline__ LdsScene stage_scene(const SceneDev &S, LdsPlan plan,
   C.tri_base = 4u * plan.n_nodes;
   C.n_nodes = plan.n_nodes;
   C.n_tris = plan.n_tris;
+  C.stack_lds = plan.stack_lds;
+  C.spill_stride = gridDim.x * BLOCK;
+  C.spill = plan.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
   for (uint32_t i = threadIdx.x; i < 4u * plan.n_nodes; i += BLOCK) pt_smem[(i & 3u) * plan.n_nodes + (i >> 2)] = gn[i];
   for (uint32_t i = threadIdx.x; i < 3u * plan.n_tris; i += BLOCK)
     pt_smem[C.tri_base + (i % 3u) * plan.n_tris + (i / 3u)] = gt[i];
@@ -550,7 +555,7 @@ struct Workspace {
 
 // Launch geometry of the traversal kernels for one scene.
 struct Plan {
-  int stack = 0;       // LDS stack entries per lane: 16, 32, 64 or 128
+  int stack = 0;       // LDS stack entries per lane
   int block = 0;       // threads per workgroup
   LdsPlan lds{};       // staged part of the scene
   size_t lds_bytes = 0;
@@ -569,6 +574,7 @@ struct PtScene {
   uint64_t bytes = 0;
   Plan plan;
   Workspace ws;
+  uint32_t *d_spill = nullptr;             // traversal-stack spill area (deep trees only)
   uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, trace head, shade head
   unsigned long long *d_stats = nullptr;   // node boxes, triangle tests: closest [0,1], visibility [2,3]
   uint32_t *h_cnt = nullptr;               // pinned
@@ -594,6 +600,14 @@ static int make_plan(PtScene *s) {
   Plan &p = s->plan;
   p.stack = stack_class(s->max_depth);
   if (!p.stack) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  // deeper trees keep only the first entries in LDS and spill the rest to global memory, so
+  // that LDS still holds 16 waves per CU and a useful part of the tree
+  int cap = 24;
+  if (const char *e = std::getenv("PT_STACK_CAP")) {  // tuning knob
+    const int c = std::atoi(e);
+    if (c >= 4 && c <= 128) cap = c;
+  }
+  if (p.stack > cap) p.stack = cap;
   p.block = p.stack <= 32 ? 1024 : (p.stack <= 64 ? 512 : 256);
   if (const char *e = std::getenv("PT_BLOCK")) {  // tuning knob
     const int b = std::atoi(e);
@@ -628,6 +642,14 @@ static int make_plan(PtScene *s) {
   if (per_cu > by_threads) per_cu = by_threads;
   if (per_cu < 1) per_cu = 1;
   p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
+  p.lds.stack_lds = (uint32_t)p.stack;
+  p.lds.spill = nullptr;
+  if (s->max_depth > (uint32_t)p.stack) {
+    const size_t words = (size_t)p.max_blocks * p.block * (s->max_depth - (uint32_t)p.stack);
+    HIP_TRY(hipMalloc(&s->d_spill, words * sizeof(uint32_t)));
+    s->bytes += words * sizeof(uint32_t);
+    p.lds.spill = s->d_spill;
+  }
   return PT_OK;
 }
 
@@ -839,6 +861,7 @@ void pt_scene_free(PtScene *s) {
   if (s->d_mats) (void)hipFree(s->d_mats);
   if (s->d_lights) (void)hipFree(s->d_lights);
   if (s->d_ltris) (void)hipFree(s->d_ltris);
+  if (s->d_spill) (void)hipFree(s->d_spill);
   if (s->d_cnt) (void)hipFree(s->d_cnt);
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->h_cnt) (void)hipHostFree(s->h_cnt);

@@ -99,13 +99,14 @@ def atrium(n=150, columns=12, seg=48, rings=30, light_ke=10.0):
 
 
 def dense_blob(n=1871, seed=7, light_ke=10.0):
-    """One mesh: a latitude-longitude sphere of radius 1.5 about (0,0,3.5) with seeded radial noise,
-    n x n quads (n=1871 gives 7 001 282 triangles, 3.5 M shared vertices), and one vertical emitter."""
+    """One mesh: a latitude-longitude sphere of radius 1.5 about (0,0,3.5) with seeded radial noise of
+    0.3 grid spacings (a finely bumpy surface, not spikes), n x n quads (n=1871 gives 7 001 282
+    triangles, 3.5 M shared vertices), and one vertical emitter."""
     rng = np.random.default_rng(seed)
     th = np.linspace(0.0, np.pi, n + 1)
     ph = np.linspace(0.0, 2 * np.pi, n + 1)
     T, P = np.meshgrid(th, ph, indexing="ij")
-    r = 1.5 * (1.0 + 0.02 * rng.standard_normal(T.shape))
+    r = 1.5 * (1.0 + (0.3 * np.pi / n) * rng.standard_normal(T.shape))
     r[:, -1] = r[:, 0]
     r[0, :] = r[0, 0]
     r[-1, :] = r[-1, 0]

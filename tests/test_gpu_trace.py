@@ -123,3 +123,16 @@ def test_philox_matches(api):
     for ctr, key in [([0] * 4, [0] * 2), ([0xffffffff] * 4, [0xffffffff] * 2),
                      ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])]:
         assert (api.philox(ctr, key) == O.philox(ctr, key)).all()
+
+
+def test_deep_stack_spills_to_global(api, monkeypatch):
+    """A tree deeper than the LDS part of the traversal stack keeps the rest in global memory."""
+    monkeypatch.setenv("PT_STACK_CAP", "4")
+    w = util.world("atrium_small")
+    ds = api.DeviceScene(w.export())
+    assert ds.info["max_depth"] > 4
+    for label in ("primary1", "random", "surface"):
+        o, d = ray_sets("atrium_small")[label]
+        check_equal(w.castray(o, d), ds.trace_closest(o, d, api.PT_TRACE_EXACT), "spill/%s" % label)
+        assert ((w.castray(o, d)["tri"] >= 0) == ds.trace_any(o, d, api.PT_TRACE_EXACT)).all()
+    ds.close()
