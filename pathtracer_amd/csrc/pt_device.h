@@ -70,14 +70,8 @@ struct PathRng {
     sample = s;
     block = 0xffffffffu;
   }
-  uint32_t cheap = 0;
   __device__ __forceinline__ double u01(uint32_t dim) {
     const uint32_t b = dim >> 1;
-    if (cheap) {
-      uint32_t h = (pixel * 0x9E3779B9u) ^ (sample * 0x85EBCA6Bu) ^ (dim * 0xC2B2AE35u);
-      h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-      return (double)(h >> 8) * (1.0 / 16777216.0);
-    }
     if (b != block) {
       philox4x32(pixel, sample, b, 0u, k0, k1, w);
       block = b;

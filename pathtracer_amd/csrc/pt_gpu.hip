@@ -28,6 +28,9 @@ using namespace ptd;
 // ===================================================================== device side
 
 static const int kBlock = 256;  // block size of the streaming kernels (ray generation, resolve)
+static const int kScanBlock = 1024;
+static const int kScanPer = 4;
+static const int kScanSpan = kScanBlock * kScanPer;  // chunks one workgroup of k_scan_local covers
 
 struct QueueDev {  // one live path per index, arrays `cap` long
   float *ox, *oy, *oz, *dx, *dy, *dz;  // ray
@@ -59,7 +62,6 @@ struct FrameDev {
   float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
   float pi_f;            // (float)M_PI, camera.cpp:122
   uint32_t dims_per_vertex;
-  uint32_t debug;        // profiling experiments only (PT_DEBUG_FLAGS); 0 in normal use
 };
 
 // What a traversal kernel keeps in LDS (see LdsScene) and how many words of the
@@ -180,9 +182,15 @@ __device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 }
 
+// Closest hit for every queued ray.  The kernel also decides which paths go on after this
+// vertex — a path continues iff it hit something and passes Russian roulette (camera.cpp:65,
+// 118-119) — and leaves the 64-bit mask of each chunk in chunk_mask, so that the survivors'
+// places in the next queue are known (k_scan_*) before k_shade writes them.
 template <int MODE, int BLOCK, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, QueueDev q, HitDev hit,
-                                                       uint32_t *head, unsigned long long *stats) {
+__global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth,
+                                                       uint32_t n, QueueDev q, HitDev hit,
+                                                       unsigned long long *chunk_mask, uint32_t *head,
+                                                       unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   const uint32_t lane = threadIdx.x & 63;
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
       const uint32_t base = (run + c) * 64u;
       if (base >= n) break;
       const uint32_t i = base + lane;
+      bool alive = false;
       if (i < n) {
         const V3 o = mk(q.ox[i], q.oy[i], q.oz[i]);
         const V3 d = mk(q.dx[i], q.dy[i], q.dz[i]);
@@ -202,7 +211,20 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
         hit.t[i] = h.t;
         hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
         hit.mat[i] = h.mat;
+        if (h.t != __builtin_inff()) {
+          alive = depth <= F.rr_min_depth;
+          if (!alive) {  // the roulette draw exists only when depth > rr_min_depth
+            const uint32_t id = q.id[i];
+            PathRng rng;
+            rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
+            const uint32_t dim = 2u + (uint32_t)depth * F.dims_per_vertex + 3u * S.n_lights;
+            alive = (double)rng.real(0.0f, 1.0f, dim) < (double)F.rr_prob;
+          }
+          if (F.max_depth > 0 && depth >= F.max_depth) alive = false;
+        }
       }
+      const unsigned long long m = __ballot(alive);
+      if (lane == 0) chunk_mask[run + c] = m;
     }
   }
   if (COUNT) {
@@ -295,17 +317,19 @@ __device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
   return add(add(scale(t1, lx), scale(t2, ly)), scale(n, lz));
 }
 
-// One path vertex per work item.  A surviving path is written back at its own index of `out`
-// and the chunk's 64-bit survivor mask to chunk_mask; k_scan_* and k_compact then pack the
-// survivors (a stable compaction: the queue stays in pixel order and no two launches differ).
+// One path vertex per work item.  Which paths survive was decided by k_trace_queue
+// (chunk_mask) and prefix-summed by k_scan_*, so a survivor is written straight to its place
+// in `out`: chunk offset + its rank among the chunk's survivors (wave ballot mask + popcount).
+// The compaction is stable: the queue stays in pixel order and no two launches differ.
 // Claiming an output slot per wave with an atomic on one counter instead was measured at
 // 260 ms per frame on its own: a single word takes under 100 atomics per microsecond.
 // cnt[1] = paths that hit something, cnt[3] = this kernel's work-queue head.
 template <int MODE, int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth, uint32_t n,
-                                                 QueueDev in, HitDev hit, QueueDev out, unsigned long long *chunk_mask,
-                                                 uint32_t *cnt, float *Lr, float *Lg, float *Lb,
-                                                 unsigned long long *stats) {
+                                                 QueueDev in, HitDev hit, QueueDev out,
+                                                 const unsigned long long *chunk_mask, const uint32_t *chunk_base,
+                                                 const uint32_t *block_off, uint32_t *cnt, float *Lr, float *Lg,
+                                                 float *Lb, unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   const int lane = threadIdx.x & 63;
@@ -315,10 +339,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
       run = next_run(cnt + 3, kRun);
       c = 0;
     }
-    const uint32_t chunk_base = (run + c) * 64u;
+    const uint32_t first_item = (run + c) * 64u;
     if ((uint64_t)(run + c) * 64u >= n) break;
-    const uint32_t i = chunk_base + (uint32_t)lane;
+    const uint32_t i = first_item + (uint32_t)lane;
     const bool active = i < n;
+    const unsigned long long m = chunk_mask[run + c];
+    const bool cont = (m >> lane) & 1ull;  // this path goes on (decided with the closest hit)
     bool alive = false, did_hit = false;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
     uint32_t id = 0;
@@ -343,7 +369,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
 
         PathRng rng;
         rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
-        rng.cheap = F.debug & 4u;
         const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
 
         // direct light: every light at every vertex, camera.cpp:96-115
@@ -373,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
           const V3 to = normalize(sub(point, x));
           HitRec sh;
           // camera.cpp:101-102: the light is skipped only when this ray hits nothing
-          if (!(F.debug & 1u) && !walk<MODE, true, COUNT, false>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
+          if (!walk<MODE, true, COUNT, false>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
           float c = dot(to, nrm);
           if (c < 0.0f) c = 0.0f;
           float y = dot(to, ln);
@@ -383,22 +408,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
           local = add(local, scale(scale(scale(lke, c), y), inv_area_f));
         }
 
-        // Russian roulette, camera.cpp:118-119; the draw happens only when depth > rr_min_depth
-        bool cont = depth <= F.rr_min_depth ||
-                    (double)rng.real(0.0f, 1.0f, base + 3u * S.n_lights) < (double)F.rr_prob;
-        if (F.max_depth > 0 && depth >= F.max_depth) cont = false;
+        // Russian roulette (camera.cpp:118-119) was drawn by k_trace_queue: `cont`
         if (cont) local = add(local, ke);  // camera.cpp:154
         L = add(L, mul(T, local));
         if (cont) {
           const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
           const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
           V3 w;
-          if (F.debug & 2u) {
-            const float ph = 6.2831853f * ry, zz = 1.0f - 2.0f * rx, rr = sqrtf(fmaxf(0.0f, 1.0f - zz * zz));
-            w = mk(__cosf(ph) * rr, __sinf(ph) * rr, zz);
-            if (dot(w, nrm) < 0.0f) w = neg(w);
-            T = divs(scale(mul(T, divs(kd, F.pi_f)), fabsf(dot(nrm, w))), F.pdf_f);
-          } else if (F.sampling == PT_SAMPLE_COSINE) {
+          if (F.sampling == PT_SAMPLE_COSINE) {
             w = cosine_dir(nrm, rx, ry);
             T = divs(mul(T, kd), F.rr_prob);
           } else {
@@ -412,15 +429,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
         }
       }
     }
-    const unsigned long long m = __ballot(alive);
     n_hit += (uint32_t)__popcll(__ballot(did_hit));
-    if (lane == 0) chunk_mask[run + c] = m;
     if (alive) {
-      out.ox[i] = o.x; out.oy[i] = o.y; out.oz[i] = o.z;
-      out.dx[i] = d.x; out.dy[i] = d.y; out.dz[i] = d.z;
-      out.tx[i] = T.x; out.ty[i] = T.y; out.tz[i] = T.z;
-      out.lx[i] = L.x; out.ly[i] = L.y; out.lz[i] = L.z;
-      out.id[i] = id;
+      const uint32_t j = block_off[(run + c) / kScanSpan] + chunk_base[run + c] +
+                         (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      out.ox[j] = o.x; out.oy[j] = o.y; out.oz[j] = o.z;
+      out.dx[j] = d.x; out.dy[j] = d.y; out.dz[j] = d.z;
+      out.tx[j] = T.x; out.ty[j] = T.y; out.tz[j] = T.z;
+      out.lx[j] = L.x; out.ly[j] = L.y; out.lz[j] = L.z;
+      out.id[j] = id;
     } else if (active) {
       Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
     }
@@ -435,9 +452,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
 // Exclusive prefix sums of the survivor counts popcount(chunk_mask[c]), two levels:
 // k_scan_local scans kScanSpan chunks per workgroup and leaves each workgroup's total in
 // block_tot; k_scan_top scans those totals in place and writes the grand total to *total.
-static const int kScanBlock = 1024;
-static const int kScanPer = 4;
-static const int kScanSpan = kScanBlock * kScanPer;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_t &block_total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -492,24 +506,6 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t n_blocks, uint
   const uint32_t ex = block_exclusive_scan(v, wave_tot, all);
   if (threadIdx.x < n_blocks) block_tot[threadIdx.x] = ex;
   if (threadIdx.x == 0) *total = all;
-}
-
-// Packs the survivors of `src` (left at their own indices by k_shade) into the front of `dst`.
-__global__ __launch_bounds__(kBlock) void k_compact(uint32_t n_chunks, const unsigned long long *chunk_mask,
-                                                    const uint32_t *chunk_base, const uint32_t *block_off, QueueDev src,
-                                                    QueueDev dst) {
-  const uint32_t chunk = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (chunk >= n_chunks) return;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long m = chunk_mask[chunk];
-  if (!((m >> lane) & 1ull)) return;
-  const uint32_t j = block_off[chunk / kScanSpan] + chunk_base[chunk] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  const uint32_t i = chunk * 64u + (uint32_t)lane;
-  dst.ox[j] = src.ox[i]; dst.oy[j] = src.oy[i]; dst.oz[j] = src.oz[i];
-  dst.dx[j] = src.dx[i]; dst.dy[j] = src.dy[i]; dst.dz[j] = src.dz[i];
-  dst.tx[j] = src.tx[i]; dst.ty[j] = src.ty[i]; dst.tz[j] = src.tz[i];
-  dst.lx[j] = src.lx[i]; dst.ly[j] = src.ly[i]; dst.lz[j] = src.lz[i];
-  dst.id[j] = src.id[i];
 }
 
 // accum[p] += sum over the batch's samples, in sample order (so the float sum does not
@@ -723,14 +719,14 @@ static int dispatch_plan(const Plan &p, F &&f) {
 }
 
 template <int MODE, bool COUNT>
-static int launch_trace_queue(PtScene *s, uint32_t n, const QueueDev &q, hipStream_t st) {
+static int launch_trace_queue(PtScene *s, const FrameDev &F, int depth, uint32_t n, const QueueDev &q, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
     auto k = k_trace_queue<MODE, BLOCK, COUNT>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
-    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, q,
-                       s->ws.hit, s->d_cnt + 2, s->d_stats);
+    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n, q,
+                       s->ws.hit, s->ws.chunk_mask, s->d_cnt + 2, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -746,7 +742,7 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
     if (rc != PT_OK) return rc;
     const Workspace &w = s->ws;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n,
-                       in, w.hit, out, w.chunk_mask, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+                       in, w.hit, out, w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -813,7 +809,6 @@ static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const Pt
   F.pdf_f = (float)(1 / (2 * M_PI) * (double)o.rr_prob);
   F.pi_f = (float)M_PI;
   F.dims_per_vertex = (3u * n_lights + 3u + 1u) & ~1u;
-  if (const char *e = std::getenv("PT_DEBUG_FLAGS")) F.debug = (uint32_t)std::atoi(e);
   return PT_OK;
 }
 
@@ -1138,25 +1133,22 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
       if ((rc = elapsed(0, 3, s->prof.other_ms)) != PT_OK) return rc;
     }
     c.paths += n;
+    int cur = 0;  // q[cur] holds the live paths, q[cur ^ 1] receives the survivors
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
       HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 4 * sizeof(uint32_t), st));
       if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
-      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, n, w.q[0], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, n, w.q[0], st);
-      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, n, w.q[0], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, n, w.q[0], st);
+      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], st);
+      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], st);
       if (rc != PT_OK) return rc;
+      const uint32_t n_chunks = (n + 63) / 64, n_sblocks = (n_chunks + kScanSpan - 1) / kScanSpan;
+      hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n_chunks, w.chunk_mask, w.chunk_base, w.block_tot);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, s->d_cnt);
+      HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
-      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[0], w.q[1], st) : launch_shade<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[0], w.q[1], st);
-      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, F, depth, n, w.q[0], w.q[1], st) : launch_shade<PT_TRACE_FAST, false>(s, F, depth, n, w.q[0], w.q[1], st);
+      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st);
+      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st);
       if (rc != PT_OK) return rc;
-      {
-        const uint32_t n_chunks = (n + 63) / 64, n_sblocks = (n_chunks + kScanSpan - 1) / kScanSpan;
-        hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n_chunks, w.chunk_mask, w.chunk_base, w.block_tot);
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, s->d_cnt);
-        hipLaunchKernelGGL(k_compact, dim3((n_chunks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, n_chunks,
-                           w.chunk_mask, w.chunk_base, w.block_tot, w.q[1], w.q[0]);
-        HIP_TRY(hipGetLastError());
-      }
       if (prof) HIP_TRY(hipEventRecord(s->ev[2], st));
       HIP_TRY(hipMemcpyAsync(s->h_cnt, s->d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -1166,6 +1158,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
         s->prof.trace_launches += 1;
         s->prof.shade_launches += 1;
       }
+      cur ^= 1;
       c.rays_closest += n;
       c.rays_shadow += (uint64_t)s->h_cnt[1] * s->dev.n_lights;
       c.bounce_passes += 1;
