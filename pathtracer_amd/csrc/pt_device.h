@@ -134,6 +134,52 @@ __device__ __forceinline__ bool tri_test(float4 a, float4 b, float4 c, V3 o, V3 
   return true;
 }
 
+// Two triangles at once, one in each half of a packed-float pair.  gfx950 executes
+// v_pk_mul_f32 / v_pk_add_f32 (two IEEE single operations per lane) in the time of one
+// scalar-per-lane operation, and these kernels are bound by vector-instruction issue, so the
+// multiplies and adds of Möller–Trumbore are written on float pairs.  Each element still gets
+// exactly the operations and roundings of tri_test (no FMA: -ffp-contract=off).  Branch-free:
+// in a divergent wave an early return saves nothing unless all 64 lanes take it.
+typedef float pt_f2 __attribute__((ext_vector_type(2)));
+struct V3x2 {
+  pt_f2 x, y, z;
+};
+__device__ __forceinline__ pt_f2 splat2(float a) { pt_f2 r = {a, a}; return r; }
+__device__ __forceinline__ pt_f2 pair2(float a, float b) { pt_f2 r = {a, b}; return r; }
+__device__ __forceinline__ V3x2 cross2(V3x2 a, V3x2 b) {
+  V3x2 r;
+  r.x = a.y * b.z - a.z * b.y;
+  r.y = a.z * b.x - a.x * b.z;
+  r.z = a.x * b.y - a.y * b.x;
+  return r;
+}
+__device__ __forceinline__ pt_f2 dot2(V3x2 a, V3x2 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+__device__ __forceinline__ void tri_test2(float4 a0, float4 b0, float4 c0, float4 a1, float4 b1, float4 c1, V3 o, V3 d,
+                                          bool &hit0, bool &hit1, pt_f2 &t, pt_f2 &u, pt_f2 &v) {
+  V3x2 v0, e1, e2, dd, oo;
+  v0.x = pair2(a0.x, a1.x); v0.y = pair2(a0.y, a1.y); v0.z = pair2(a0.z, a1.z);
+  e1.x = pair2(a0.w, a1.w); e1.y = pair2(b0.x, b1.x); e1.z = pair2(b0.y, b1.y);
+  e2.x = pair2(b0.z, b1.z); e2.y = pair2(b0.w, b1.w); e2.z = pair2(c0.x, c1.x);
+  dd.x = splat2(d.x); dd.y = splat2(d.y); dd.z = splat2(d.z);
+  oo.x = splat2(o.x); oo.y = splat2(o.y); oo.z = splat2(o.z);
+  const V3x2 pv = cross2(dd, e2);
+  const pt_f2 n = dot2(pv, e1);
+  V3x2 tv;
+  tv.x = oo.x - v0.x; tv.y = oo.y - v0.y; tv.z = oo.z - v0.z;
+  const pt_f2 inv = pair2(1.0f / n.x, 1.0f / n.y);
+  u = inv * dot2(pv, tv);
+  const V3x2 c = cross2(tv, e1);
+  V3x2 q;
+  q.x = c.x * inv; q.y = c.y * inv; q.z = c.z * inv;
+  v = dot2(q, dd);
+  t = dot2(q, e2);
+  const pt_f2 uv = u + v;
+  // object.cpp:412,417,422,426; (double)t < 1e-6 holds exactly when t <= 1e-6f, the float just below 1e-6
+  hit0 = n.x != 0.0f && !(u.x < 0.0f || u.x > 1.0f) && !(v.x < 0.0f || uv.x > 1.0f) && !(t.x <= 1e-6f);
+  hit1 = n.y != 0.0f && !(u.y < 0.0f || u.y > 1.0f) && !(v.y < 0.0f || uv.y > 1.0f) && !(t.y <= 1e-6f);
+}
+
 // The part of the scene a workgroup keeps in LDS: the first n_nodes nodes (the tree is
 // numbered breadth-first from the root, so these are its top levels) and, when the whole
 // triangle table fits, all triangles.  Both are stored split by 16-byte piece: piece k of
@@ -247,25 +293,16 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
       if (COUNT) n_boxes += 2;
       // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
       const float far = (MODE == PT_TRACE_FAST && !ANY) ? cull : __builtin_inff();
-      float tn0 = 1e-5f, tf0 = far, tn1 = 1e-5f, tf1 = far;
-      {
-        const float a0 = ((sx ? q0.w : q0.x) - on.x) * ix, b0 = ((sx ? q0.x : q0.w) - of.x) * ix;
-        const float a1 = ((sx ? q2.y : q1.z) - on.x) * ix, b1 = ((sx ? q1.z : q2.y) - of.x) * ix;
-        tn0 = fmaxf(tn0, a0); tf0 = fminf(tf0, b0);
-        tn1 = fmaxf(tn1, a1); tf1 = fminf(tf1, b1);
-      }
-      {
-        const float a0 = ((sy ? q1.x : q0.y) - on.y) * iy, b0 = ((sy ? q0.y : q1.x) - of.y) * iy;
-        const float a1 = ((sy ? q2.z : q1.w) - on.y) * iy, b1 = ((sy ? q1.w : q2.z) - of.y) * iy;
-        tn0 = fmaxf(tn0, a0); tf0 = fminf(tf0, b0);
-        tn1 = fmaxf(tn1, a1); tf1 = fminf(tf1, b1);
-      }
-      {
-        const float a0 = ((sz ? q1.y : q0.z) - on.z) * iz, b0 = ((sz ? q0.z : q1.y) - of.z) * iz;
-        const float a1 = ((sz ? q2.w : q2.x) - on.z) * iz, b1 = ((sz ? q2.x : q2.w) - of.z) * iz;
-        tn0 = fmaxf(tn0, a0); tf0 = fminf(tf0, b0);
-        tn1 = fmaxf(tn1, a1); tf1 = fminf(tf1, b1);
-      }
+      // both children side by side in packed pairs: (plane - origin) * (1/d), object.cpp:184-185
+      const pt_f2 ax = (pair2(sx ? q0.w : q0.x, sx ? q2.y : q1.z) - splat2(on.x)) * splat2(ix);
+      const pt_f2 bx = (pair2(sx ? q0.x : q0.w, sx ? q1.z : q2.y) - splat2(of.x)) * splat2(ix);
+      const pt_f2 ay = (pair2(sy ? q1.x : q0.y, sy ? q2.z : q1.w) - splat2(on.y)) * splat2(iy);
+      const pt_f2 by = (pair2(sy ? q0.y : q1.x, sy ? q1.w : q2.z) - splat2(of.y)) * splat2(iy);
+      const pt_f2 az = (pair2(sz ? q1.y : q0.z, sz ? q2.w : q2.x) - splat2(on.z)) * splat2(iz);
+      const pt_f2 bz = (pair2(sz ? q0.z : q1.y, sz ? q2.x : q2.w) - splat2(of.z)) * splat2(iz);
+      // tmin starts at EPSILON, tmax at the cull distance; NaN never updates (object.cpp:180,188-191)
+      const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax.x), ay.x), az.x), tf0 = fminf(fminf(fminf(far, bx.x), by.x), bz.x);
+      const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax.y), ay.y), az.y), tf1 = fminf(fminf(fminf(far, bx.y), by.y), bz.y);
       bool p0, p1;
       if (MODE == PT_TRACE_EXACT) {
         // only an internal node of the reference tree is box-tested there (object.cpp:277)
@@ -290,31 +327,44 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
       const uint32_t first = cur & ptl::REF_FIRST_MASK;
       const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
       const bool in_lds = first + cnt <= C.n_tris;
-      for (uint32_t k = 0; k < cnt; ++k) {
-        float t, u, v;
-        if (COUNT) ++n_tris;
-        float4 ta, tb, tc;
+      for (uint32_t k = 0; k < cnt; k += 2) {
+        // an odd last triangle is paired with itself and its second copy ignored
+        const bool two = k + 1 < cnt;
+        const uint32_t s0 = first + k, s1 = two ? s0 + 1 : s0;
+        if (COUNT) n_tris += two ? 2u : 1u;
+        float4 a0, b0, c0, a1, b1, c1;
         if (in_lds) {
-          const uint32_t at = C.tri_base + first + k;
-          ta = lds_f4(at); tb = lds_f4(at + C.n_tris); tc = lds_f4(at + 2u * C.n_tris);
+          const uint32_t at0 = C.tri_base + s0, at1 = C.tri_base + s1;
+          a0 = lds_f4(at0); b0 = lds_f4(at0 + C.n_tris); c0 = lds_f4(at0 + 2u * C.n_tris);
+          a1 = lds_f4(at1); b1 = lds_f4(at1 + C.n_tris); c1 = lds_f4(at1 + 2u * C.n_tris);
         } else {
-          const size_t at = 3u * (size_t)(first + k);
-          ta = glb_f4(S.tris, at); tb = glb_f4(S.tris, at + 1); tc = glb_f4(S.tris, at + 2);
+          const size_t at0 = 3u * (size_t)s0, at1 = 3u * (size_t)s1;
+          a0 = glb_f4(S.tris, at0); b0 = glb_f4(S.tris, at0 + 1); c0 = glb_f4(S.tris, at0 + 2);
+          a1 = glb_f4(S.tris, at1); b1 = glb_f4(S.tris, at1 + 1); c1 = glb_f4(S.tris, at1 + 2);
         }
-        if (tri_test(ta, tb, tc, o, d, t, u, v)) {
-          if (ANY) return true;
+        bool h0, h1;
+        pt_f2 t2, u2, v2;
+        tri_test2(a0, b0, c0, a1, b1, c1, o, d, h0, h1, t2, u2, v2);
+        h1 = h1 && two;
+        if (ANY) {
+          if (h0 || h1) return true;
+        } else {
           // larger slot wins a tie: the reference's leftmost-in-leaf / right-sibling rule
-          if (t < best.t || (t == best.t && (int32_t)(first + k) > (int32_t)best.slot)) {
-            best.t = t;
-            best.slot = first + k;
-            best.u = u;
-            best.v = v;
+          if (h0 && (t2.x < best.t || (t2.x == best.t && (int32_t)s0 > (int32_t)best.slot))) {
+            best.t = t2.x; best.slot = s0; best.u = u2.x; best.v = v2.x;
             if (WANT_N) {
-              best.n = cross(mk(ta.w, tb.x, tb.y), mk(tb.z, tb.w, tc.x));  // (v1-v0) x (v2-v0), object.cpp:393
-              best.mat = __float_as_uint(tc.z);
+              best.n = cross(mk(a0.w, b0.x, b0.y), mk(b0.z, b0.w, c0.x));  // (v1-v0) x (v2-v0), object.cpp:393
+              best.mat = __float_as_uint(c0.z);
             }
-            if (MODE == PT_TRACE_FAST) cull = t + (t * PT_SLACK_REL + PT_SLACK_ABS);
           }
+          if (h1 && (t2.y < best.t || (t2.y == best.t && (int32_t)s1 > (int32_t)best.slot))) {
+            best.t = t2.y; best.slot = s1; best.u = u2.y; best.v = v2.y;
+            if (WANT_N) {
+              best.n = cross(mk(a1.w, b1.x, b1.y), mk(b1.z, b1.w, c1.x));
+              best.mat = __float_as_uint(c1.z);
+            }
+          }
+          if (MODE == PT_TRACE_FAST) cull = best.t + (best.t * PT_SLACK_REL + PT_SLACK_ABS);
         }
       }
     }

@@ -640,6 +640,9 @@ static int make_plan(PtScene *s) {
   p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
   p.lds.stack_lds = (uint32_t)p.stack;
   p.lds.spill = nullptr;
+  if (std::getenv("PT_VERBOSE"))
+    std::fprintf(stderr, "ptgpu plan: depth %u, block %d, LDS stack %d entries/lane, %u nodes + %u triangles in LDS, %zu B LDS per workgroup, %u resident workgroups\n",
+                 s->max_depth, p.block, p.stack, p.lds.n_nodes, p.lds.n_tris, p.lds_bytes, p.max_blocks);
   if (s->max_depth > (uint32_t)p.stack) {
     const size_t words = (size_t)p.max_blocks * p.block * (s->max_depth - (uint32_t)p.stack);
     HIP_TRY(hipMalloc(&s->d_spill, words * sizeof(uint32_t)));

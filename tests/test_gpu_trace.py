@@ -136,3 +136,29 @@ def test_deep_stack_spills_to_global(api, monkeypatch):
         check_equal(w.castray(o, d), ds.trace_closest(o, d, api.PT_TRACE_EXACT), "spill/%s" % label)
         assert ((w.castray(o, d)["tri"] >= 0) == ds.trace_any(o, d, api.PT_TRACE_EXACT)).all()
     ds.close()
+
+
+@pytest.mark.parametrize("name,builder", [
+    ("atrium260k", lambda: __import__("pathtracer_amd.scenes", fromlist=["x"]).atrium(150)),
+    ("blob1m", lambda: __import__("pathtracer_amd.scenes", fromlist=["x"]).dense_blob(707)),
+])
+def test_large_scenes_bit_exact_through_the_host_builder(api, name, builder):
+    """Benchmark-sized trees (260 k and 1 M triangles), built by the product's host-side builder, walked on
+    the GPU, against the oracle's own build and recursive walk: primary, random and axis-aligned rays."""
+    from pathtracer_amd import host
+    meshes, mats = builder()
+    w = O.World.from_meshes(meshes, mats)
+    ds = host.Scene.from_meshes(meshes, mats).device_scene(0)
+    assert ds.info["n_tris"] == w.n_tris
+    sets = {
+        "primary": util.primary_rays(O.default_camera(vw=16, vh=9), 192, 108),
+        "primary_tilted": util.primary_rays(O.default_camera(origin=(0.2, 0.1, 0.4), euler=(0.1, 0.3, 0.05)), 128, 128),
+        "random": util.random_rays(20000, 5),
+        "axis": util.axis_rays(4000, 6),
+    }
+    for label, (o, d) in sets.items():
+        ref = w.castray(o, d)
+        check_equal(ref, ds.trace_closest(o, d, api.PT_TRACE_FAST), "%s/%s/fast" % (name, label))
+        if label != "axis" and label != "primary":   # exact mode walks most of the tree for axis-aligned rays
+            check_equal(ref, ds.trace_closest(o, d, api.PT_TRACE_EXACT), "%s/%s/exact" % (name, label))
+        assert ((ref["tri"] >= 0) == ds.trace_any(o, d, api.PT_TRACE_FAST)).all()
