@@ -101,6 +101,7 @@ struct SceneDev {
 struct HitRec {
   float t;
   uint32_t slot;  // 0xffffffff = miss
+  uint32_t rank;  // TriRec::rank of that triangle (tie order)
   float u, v;
   V3 n;           // Triangle::normal() of the hit triangle, un-normalised (only with WANT_N)
   uint32_t mat;   // its material id (only with WANT_N)
@@ -266,6 +267,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
   const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
   best.t = __builtin_inff();
   best.slot = 0xffffffffu;
+  best.rank = 0xffffffffu;
   best.u = 0.0f;
   best.v = 0.0f;
   if (WANT_N) {
@@ -349,16 +351,16 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
         if (ANY) {
           if (h0 || h1) return true;
         } else {
-          // larger slot wins a tie: the reference's leftmost-in-leaf / right-sibling rule
-          if (h0 && (t2.x < best.t || (t2.x == best.t && (int32_t)s0 > (int32_t)best.slot))) {
-            best.t = t2.x; best.slot = s0; best.u = u2.x; best.v = v2.x;
+          // larger rank wins a tie: the reference's leftmost-in-leaf / right-sibling rule
+          if (h0 && (t2.x < best.t || (t2.x == best.t && (int32_t)__float_as_uint(c0.w) > (int32_t)best.rank))) {
+            best.t = t2.x; best.slot = s0; best.rank = __float_as_uint(c0.w); best.u = u2.x; best.v = v2.x;
             if (WANT_N) {
               best.n = cross(mk(a0.w, b0.x, b0.y), mk(b0.z, b0.w, c0.x));  // (v1-v0) x (v2-v0), object.cpp:393
               best.mat = __float_as_uint(c0.z);
             }
           }
-          if (h1 && (t2.y < best.t || (t2.y == best.t && (int32_t)s1 > (int32_t)best.slot))) {
-            best.t = t2.y; best.slot = s1; best.u = u2.y; best.v = v2.y;
+          if (h1 && (t2.y < best.t || (t2.y == best.t && (int32_t)__float_as_uint(c1.w) > (int32_t)best.rank))) {
+            best.t = t2.y; best.slot = s1; best.rank = __float_as_uint(c1.w); best.u = u2.y; best.v = v2.y;
             if (WANT_N) {
               best.n = cross(mk(a1.w, b1.x, b1.y), mk(b1.z, b1.w, c1.x));
               best.mat = __float_as_uint(c1.z);

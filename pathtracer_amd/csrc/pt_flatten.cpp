@@ -7,13 +7,19 @@
 // meshes inside a top-level leaf are never box-tested — and (b) a tie rule among
 // equal t: inside a leaf the leftmost minimum wins (std::ranges::min), between
 // siblings the right child wins (`lhit.t < rhit.t ? lhit : rhit`).  Rule (b) is a
-// total order over triangle positions, so triangles are stored in that order and
-// "larger slot wins a tie" reproduces it for any visiting order.  Rule (a) is kept
-// by tagging each child slot with its kind (pt_layout.h).
+// total order over triangle positions, so every triangle carries its position in
+// that order as `rank` and "larger rank wins a tie" reproduces it for any visiting
+// order.  Rule (a) is kept by tagging each child slot with its kind (pt_layout.h).
+//
+// A reference leaf holds up to 8 triangles.  Here it becomes a small subtree of
+// GROUP nodes over leaves of at most `leaf_size` triangles, split at the spatial
+// median: the exact mode visits all of it (as the reference visits the whole leaf),
+// the fast mode box-tests its way down and so tests a few triangles instead of 8.
 #include "pt_flatten.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 
@@ -40,6 +46,7 @@ struct Flattener {
   std::vector<uint8_t> tlas_seen;
   std::vector<uint8_t> blas_seen;    // per global blas node
   uint32_t next_slot = 0;
+  uint32_t leaf_size = 2;            // triangles per device leaf (1..8)
   bool failed = false;
 
   Flattener(const PtSceneDesc &dd, FlatScene &o, std::string &e) : d(dd), out(o), err(e) {}
@@ -126,6 +133,68 @@ struct Flattener {
     return g;  // union of already widened boxes
   }
 
+  // Exact bounds of the triangles in slots [lo, hi), from the vertices as given.
+  Entry slot_bounds(uint32_t lo, uint32_t hi) const {
+    Entry e;
+    for (int k = 0; k < 3; ++k) {
+      e.lo[k] = INFINITY;
+      e.hi[k] = -INFINITY;
+    }
+    for (uint32_t s = lo; s < hi; ++s) {
+      const float *p = d.tri_verts + (size_t)out.tris[s].tri_id * 9;
+      for (int v = 0; v < 3; ++v)
+        for (int k = 0; k < 3; ++k) {
+          e.lo[k] = std::min(e.lo[k], p[3 * v + k]);   // NaN coordinates leave the box alone
+          e.hi[k] = std::max(e.hi[k], p[3 * v + k]);
+        }
+    }
+    return e;
+  }
+
+  // Device subtree for one reference leaf whose triangles sit in slots [lo, hi): records are
+  // reordered in place (their ranks travel with them), sorted along the axis of largest centroid
+  // extent and cut so the left part is a whole number of device leaves.
+  Entry split_leaf(uint32_t lo, uint32_t hi) {
+    const uint32_t n = hi - lo;
+    if (n <= leaf_size) {
+      Entry c = slot_bounds(lo, hi);
+      c.ref = REF_LEAF | ((n - 1) << 28) | lo;
+      c.kind = KIND_LEAF;
+      c.depth = 0;
+      widen(c);
+      return c;
+    }
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto centroid = [&](const TriRec &r, int k) {
+      const float *p = d.tri_verts + (size_t)r.tri_id * 9;
+      return p[k] + p[3 + k] + p[6 + k];
+    };
+    for (uint32_t s = lo; s < hi; ++s)
+      for (int k = 0; k < 3; ++k) {
+        const float c = centroid(out.tris[s], k);
+        cmin[k] = std::min(cmin[k], c);
+        cmax[k] = std::max(cmax[k], c);
+      }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+      if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+    std::stable_sort(out.tris.begin() + lo, out.tris.begin() + hi, [&](const TriRec &a, const TriRec &b) {
+      return centroid(a, axis) < centroid(b, axis);
+    });
+    const uint32_t leaves = (n + leaf_size - 1) / leaf_size;
+    const uint32_t mid = lo + std::min(n - 1, (leaves + 1) / 2 * leaf_size);
+    Entry a = split_leaf(lo, mid), b = split_leaf(mid, hi);
+    Entry g;
+    for (int k = 0; k < 3; ++k) {
+      g.lo[k] = std::min(a.lo[k], b.lo[k]);
+      g.hi[k] = std::max(a.hi[k], b.hi[k]);
+    }
+    g.ref = make_node(a, b);
+    g.kind = KIND_GROUP;
+    g.depth = 1 + std::max(a.depth, b.depth);
+    return g;
+  }
+
   void put_triangle(uint32_t mesh, uint32_t local) {
     const uint32_t gid = d.tri_offset[mesh] + local;
     const float *p = d.tri_verts + (size_t)gid * 9;
@@ -139,7 +208,7 @@ struct Flattener {
       if (std::isfinite(p[k])) out.max_abs_coord = std::max(out.max_abs_coord, std::fabs(p[k]));
     r.tri_id = gid;
     r.mat_id = d.mesh_material[mesh];
-    r.mesh_id = mesh;
+    r.rank = next_slot;
     out.tris.push_back(r);
     ++next_slot;
   }
@@ -165,17 +234,7 @@ struct Flattener {
         put_triangle(mesh, local_tri);
       }
       if (next_slot > MAX_TRI_SLOTS) return fail("more than 2^28 triangles");
-      std::vector<Entry> chunks;
-      for (uint32_t s = first_slot; s < next_slot; s += 8) {
-        Entry c = e;
-        const uint32_t cnt = std::min<uint32_t>(8, next_slot - s);
-        c.ref = REF_LEAF | ((cnt - 1) << 28) | s;
-        c.kind = KIND_LEAF;
-        c.depth = 0;
-        widen(c);
-        chunks.push_back(c);
-      }
-      return group(chunks, 0, chunks.size());
+      return split_leaf(first_slot, next_slot);
     }
     Entry l = mesh_node(mesh, n.index_or_first, level + 1);
     Entry r = mesh_node(mesh, n.index_or_first + 1, level + 1);
@@ -334,6 +393,10 @@ struct Flattener {
     mesh_seen.assign(d.n_meshes, 0);
     tlas_seen.assign(d.n_tlas_nodes, 0);
     blas_seen.assign(d.blas_node_offset[d.n_meshes], 0);
+    if (const char *e = std::getenv("PT_LEAF")) {  // tuning knob: triangles per device leaf
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 8) leaf_size = (uint32_t)v;
+    }
     out.tris.reserve((size_t)d.n_tris + 1);
     Entry root = tlas_node(0, 0);
     if (failed) return PT_ERR_INVALID;

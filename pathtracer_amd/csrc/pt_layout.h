@@ -49,7 +49,7 @@ struct alignas(16) TriRec {
   float e2[3];
   uint32_t tri_id;   // global triangle id in file order
   uint32_t mat_id;
-  uint32_t mesh_id;
+  uint32_t rank;     // position in the reference's tie order: of two hits at equal t the larger rank wins
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
