@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented pass (roofline becomes null)")
     ap.add_argument("--max-depth", type=int, default=-1)
     ap.add_argument("--aperture", type=float, default=-1.0)
+    ap.add_argument("--others", dest="others", action="store_true", default=True,
+                    help="after the main run, one short frame of each other named configuration (default)")
+    ap.add_argument("--no-others", dest="others", action="store_false")
     return ap.parse_args()
 
 
@@ -76,39 +79,33 @@ def cpu_baseline(meshes, mats, cfg, cam_kw, opt_kw):
     }
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                         "--nproc-per-node %d" % (args.gpus, args.gpus))
+# Named settings of the larger configurations: the 260 k-triangle one is quoted with 5 bounces and
+# depth of field on.  `spp` here is the short sample count of the secondary report lines.
+OTHERS = {
+    "atrium260k": dict(spp=16, max_depth=5, aperture=0.05),
+    "blob7m": dict(spp=4),
+    "terrain1m": dict(spp=1),
+}
 
-    import numpy as np
+
+def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank, local_rank, world, dev):
+    """Builds the scene, renders `warmup` untimed and `steps` timed frames of it and returns the
+    measurements (on every rank; sums and the slowest rank's time are already reduced)."""
     import torch
     import torch.distributed as dist
     from pathtracer_amd import api, host
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-
-    cfg = workload(args)
     W, H, spp = cfg["W"], cfg["H"], cfg["spp"]
     meshes, mats = cfg["scene"]()
     scene = host.Scene.from_meshes(meshes, mats)
     ds = scene.device_scene(local_rank)
     cam_kw = dict(cfg["cam"])
-    if args.aperture >= 0:
-        cam_kw.update(aperture=args.aperture, focus=3.0)
+    if aperture >= 0:
+        cam_kw.update(aperture=aperture, focus=3.0)
     cam = api.make_camera(**cam_kw)
-    opt_kw = dict(trace_mode=api.PT_TRACE_FAST if args.mode == "fast" else api.PT_TRACE_EXACT)
-    if args.max_depth >= 0:
-        opt_kw["max_depth"] = args.max_depth
+    opt_kw = dict(trace_mode=api.PT_TRACE_FAST if mode == "fast" else api.PT_TRACE_EXACT)
+    if max_depth >= 0:
+        opt_kw["max_depth"] = max_depth
     opt = api.make_options(spp_stride=world, **opt_kw)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -123,13 +120,13 @@ def main():
     # instrumented pass: node boxes and triangles the closest-hit kernel reads for exactly this
     # frame (the sample indices are the same, so the counts are those of every timed step)
     counts = None
-    if not args.no_count:
+    if count:
         ds.count_stats(True)
         counts = step()
         torch.cuda.synchronize()
         ds.count_stats(False)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     ds.profile(True)
@@ -139,7 +136,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    for _ in range(steps):
         last = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -157,55 +154,116 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
     all_rays, all_paths = float(tot[1]), float(tot[2])
-    finite = bool(torch.isfinite(accum).all())
-
-    if rank == 0:
-        K = max(1, args.steps)
-        out = {
-            "metric": "Mrays/s at 1080p" if H == 1080 else "Mrays/s",
-            "value": all_rays * K / dt / 1e6,
-            "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": "%s: %d triangles in %d meshes, %d area light(s), %dx%d, %d spp per GPU, %s traversal"
-                            % (args.config, ds.info["n_tris"], ds.info["n_meshes"], ds.info["n_lights"], W, H, spp,
-                               args.mode),
-                "rays_per_sample": all_rays / max(1.0, all_paths),
-                "bounce_passes": int(last.bounce_passes),
-                "max_depth": opt.max_depth, "aperture": float(cam.aperture),
-            },
-            "samples_per_s": all_paths * K / dt,
-            "finite": finite,
-            "kernel_ms_per_step": {"trace_closest": prof["trace_ms"] / K, "shade_nee": prof["shade_ms"] / K,
-                                   "raygen_resolve": prof["other_ms"] / K},
+    K = max(1, steps)
+    res = {
+        "value": all_rays * K / dt / 1e6,
+        "ms_per_step": dt / K * 1e3,
+        "samples_per_s": all_paths * K / dt,
+        "finite": bool(torch.isfinite(accum).all()),
+        "workload": "%s: %d triangles in %d meshes, %d area light(s), %dx%d, %d spp per GPU, %s traversal"
+                    % (name, ds.info["n_tris"], ds.info["n_meshes"], ds.info["n_lights"], W, H, spp, mode),
+        "rays_per_sample": all_rays / max(1.0, all_paths),
+        "bounce_passes": int(last.bounce_passes),
+        "max_depth": opt.max_depth, "aperture": float(cam.aperture),
+        "kernel_ms_per_step": {"trace_closest": prof["trace_ms"] / K, "shade_nee": prof["shade_ms"] / K,
+                               "raygen_resolve": prof["other_ms"] / K},
+        "roofline": None,
+    }
+    if counts is not None:
+        # closest-hit kernel: algorithmic bytes = 32 B per node box + 36 B per triangle + 48 B of
+        # ray in / hit out per ray, over all launches of the timed steps
+        nb, nt, nr = counts.node_boxes, counts.tri_tests, counts.rays_closest
+        bytes_step = 32.0 * nb + 36.0 * nt + 48.0 * nr
+        launches = max(1, int(prof["trace_launches"]))
+        gbs = bytes_step * K / (prof["trace_ms"] * 1e-3) / 1e9 if prof["trace_ms"] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % name)
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("trace_closest_hbm_bytes_per_launch")
+        scene_bytes = 64.0 * ds.info["n_wide_nodes"] + 48.0 * ds.info["n_tris"]
+        res["roofline"] = {
+            "bound": "hbm", "kernel": "k_trace_queue (closest hit)",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_step * K / launches,
+            "avg_launch_ms": prof["trace_ms"] / launches, "launches": launches,
+            "node_boxes_per_ray": nb / max(1, nr), "tri_tests_per_ray": nt / max(1, nr),
+            "shadow_node_boxes_per_ray": counts.shadow_node_boxes / max(1, counts.rays_shadow),
+            "shadow_tri_tests_per_ray": counts.shadow_tri_tests / max(1, counts.rays_shadow),
+            # the gathers counted above are served by the copy of the scene each workgroup keeps in
+            # LDS when it fits (then frac can exceed 1 and the kernel is bound by vector-instruction
+            # issue); only the ray queue and the hit records (44 B per ray) must cross HBM
+            "scene_bytes": scene_bytes,
+            "scene_lds_resident": bool(scene_bytes <= 150 * 1024),
+            "queue_bytes_gbs": 44.0 * nr * K / (prof["trace_ms"] * 1e-3) / 1e9 if prof["trace_ms"] > 0 else 0.0,
         }
-        if counts is not None:
-            # closest-hit kernel: algorithmic bytes = 32 B per node box + 36 B per triangle + 48 B of
-            # ray in / hit out per ray, over all launches of the timed steps
-            nb, nt, nr = counts.node_boxes, counts.tri_tests, counts.rays_closest
-            bytes_step = 32.0 * nb + 36.0 * nt + 48.0 * nr
-            launches = max(1, int(prof["trace_launches"]))
-            gbs = bytes_step * K / (prof["trace_ms"] * 1e-3) / 1e9 if prof["trace_ms"] > 0 else 0.0
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.config)
-            if os.path.exists(pmc):
-                with open(pmc) as f:
-                    traffic = json.load(f).get("trace_closest_hbm_bytes_per_launch")
-            out["roofline"] = {
-                "bound": "hbm", "kernel": "k_trace_queue (closest hit)",
-                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_step * K / launches,
-                "avg_launch_ms": prof["trace_ms"] / launches, "launches": launches,
-                "node_boxes_per_ray": nb / max(1, nr), "tri_tests_per_ray": nt / max(1, nr),
-                "shadow_node_boxes_per_ray": counts.shadow_node_boxes / max(1, counts.rays_shadow),
-                "shadow_tri_tests_per_ray": counts.shadow_tri_tests / max(1, counts.rays_shadow),
-            }
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(meshes, mats, cfg, cam_kw, {k: v for k, v in opt_kw.items() if k != "trace_mode"})
+    ds.close()
+    scene.close()
+    return res, (meshes, mats, cam_kw, {k: v for k, v in opt_kw.items() if k != "trace_mode"})
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import scenes
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = workload(args)
+    res, (meshes, mats, cam_kw, opt_kw) = run_config(args.config, cfg, args.mode, args.max_depth, args.aperture,
+                                                     args.steps, args.warmup, not args.no_count, rank, local_rank,
+                                                     world, dev)
+    out = {
+        "metric": "Mrays/s at 1080p" if cfg["H"] == 1080 else "Mrays/s",
+        "value": res["value"], "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": res["workload"], "rays_per_sample": res["rays_per_sample"],
+                   "bounce_passes": res["bounce_passes"], "max_depth": res["max_depth"], "aperture": res["aperture"]},
+        "samples_per_s": res["samples_per_s"], "finite": res["finite"],
+        "kernel_ms_per_step": res["kernel_ms_per_step"],
+    }
+    if res["roofline"] is not None:
+        out["roofline"] = res["roofline"]
+    if world == 1 and rank == 0 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(meshes, mats, cfg, cam_kw, opt_kw)
+    del meshes, mats
+
+    # the other named configurations, one short frame each (rates do not depend on spp): same
+    # sharding over the ranks, same counters; these are report lines, `value` above is the metric
+    if args.others and args.config == "box1k":
+        others = []
+        for name, kw in OTHERS.items():
+            c = dict(scenes.CONFIGS[name])
+            c["spp"] = kw["spp"]
+            r, _ = run_config(name, c, args.mode, kw.get("max_depth", -1), kw.get("aperture", -1.0), 1, 1,
+                              not args.no_count, rank, local_rank, world, dev)
+            others.append({
+                "workload": r["workload"], "value": r["value"], "unit": "Mrays/s", "ms_per_step": r["ms_per_step"],
+                "samples_per_s": r["samples_per_s"], "max_depth": r["max_depth"], "aperture": r["aperture"],
+                "kernel_ms_per_step": r["kernel_ms_per_step"], "finite": r["finite"],
+                "roofline_frac": None if r["roofline"] is None else r["roofline"]["frac"],
+                "node_boxes_per_ray": None if r["roofline"] is None else r["roofline"]["node_boxes_per_ray"],
+                "tri_tests_per_ray": None if r["roofline"] is None else r["roofline"]["tri_tests_per_ray"],
+            })
+        out["other_configs"] = others
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
