@@ -223,12 +223,14 @@ struct LdsScene {
   uint32_t spill_stride;  // distance between a lane's consecutive spill entries, in words
 };
 
+template <bool RES>
 __device__ __forceinline__ void push_ref(const LdsScene &C, uint32_t stk, uint32_t stride, int sp, uint32_t v) {
-  if ((uint32_t)sp < C.stack_lds) stack_put(stk + (uint32_t)sp * stride, v);
+  if (RES || (uint32_t)sp < C.stack_lds) stack_put(stk + (uint32_t)sp * stride, v);
   else C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride] = v;
 }
+template <bool RES>
 __device__ __forceinline__ uint32_t pop_ref(const LdsScene &C, uint32_t stk, uint32_t stride, int sp) {
-  if ((uint32_t)sp < C.stack_lds) return stack_get(stk + (uint32_t)sp * stride);
+  if (RES || (uint32_t)sp < C.stack_lds) return stack_get(stk + (uint32_t)sp * stride);
   return C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride];
 }
 
@@ -243,7 +245,10 @@ __device__ __forceinline__ uint32_t pop_ref(const LdsScene &C, uint32_t stk, uin
 // so every step advances every live lane.  A nested "nodes until a leaf, then the leaf"
 // shape was measured twice as slow: the wave then takes the longest node run of any lane
 // in every round, and node steps are the expensive ones.
-template <int MODE, bool ANY, bool COUNT, bool WANT_N = false>
+//
+// RES: the launch keeps every node, every triangle and the whole stack in LDS (small scenes);
+// the tests that choose between LDS and global memory then fall away at compile time.
+template <int MODE, bool ANY, bool COUNT, bool WANT_N = false, bool RES = false>
 __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o, V3 d, uint32_t stk, uint32_t stride,
                                      HitRec &best, uint32_t &n_boxes, uint32_t &n_tris) {
   // 1/d per axis as AABB::intersect forms it (object.cpp:183).  An axis with d == 0 is
@@ -281,7 +286,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
     if (!(cur & ptl::REF_LEAF)) {
       float4 q0, q1, q2;
       uint4 q3;
-      if (cur < C.n_nodes) {
+      if (RES || cur < C.n_nodes) {
         const uint32_t at = C.node_base + cur;
         q0 = lds_f4(at); q1 = lds_f4(at + C.n_nodes); q2 = lds_f4(at + 2u * C.n_nodes);
         const float4 r = lds_f4(at + 3u * C.n_nodes);
@@ -318,7 +323,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
       }
       if (p0 && p1) {
         const bool swap = (MODE == PT_TRACE_FAST && !ANY) ? (tn1 < tn0) : false;
-        push_ref(C, stk, stride, sp, swap ? q3.x : q3.y);
+        push_ref<RES>(C, stk, stride, sp, swap ? q3.x : q3.y);
         ++sp;
         cur = swap ? q3.y : q3.x;
         continue;
@@ -328,7 +333,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
     } else {
       const uint32_t first = cur & ptl::REF_FIRST_MASK;
       const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-      const bool in_lds = first + cnt <= C.n_tris;
+      const bool in_lds = RES || first + cnt <= C.n_tris;
       for (uint32_t k = 0; k < cnt; k += 2) {
         // an odd last triangle is paired with itself and its second copy ignored
         const bool two = k + 1 < cnt;
@@ -372,7 +377,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
     }
     if (sp == 0) break;
     --sp;
-    cur = pop_ref(C, stk, stride, sp);
+    cur = pop_ref<RES>(C, stk, stride, sp);
   }
   return best.slot != 0xffffffffu;
 }

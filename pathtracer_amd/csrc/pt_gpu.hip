@@ -186,7 +186,7 @@ __device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
 // vertex — a path continues iff it hit something and passes Russian roulette (camera.cpp:65,
 // 118-119) — and leaves the 64-bit mask of each chunk in chunk_mask, so that the survivors'
 // places in the next queue are known (k_scan_*) before k_shade writes them.
-template <int MODE, int BLOCK, bool COUNT>
+template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth,
                                                        uint32_t n, QueueDev q, HitDev hit,
                                                        unsigned long long *chunk_mask, uint32_t *head,
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
         const V3 o = mk(q.ox[i], q.oy[i], q.oz[i]);
         const V3 d = mk(q.dx[i], q.dy[i], q.dz[i]);
         HitRec h;
-        walk<MODE, false, COUNT, true>(S, C, o, d, stk, BLOCK, h, nb, nt);
+        walk<MODE, false, COUNT, true, RES>(S, C, o, d, stk, BLOCK, h, nb, nt);
         hit.t[i] = h.t;
         hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
         hit.mat[i] = h.mat;
@@ -324,7 +324,7 @@ __device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
 // Claiming an output slot per wave with an atomic on one counter instead was measured at
 // 260 ms per frame on its own: a single word takes under 100 atomics per microsecond.
 // cnt[1] = paths that hit something, cnt[3] = this kernel's work-queue head.
-template <int MODE, int BLOCK, bool COUNT>
+template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth, uint32_t n,
                                                  QueueDev in, HitDev hit, QueueDev out,
                                                  const unsigned long long *chunk_mask, const uint32_t *chunk_base,
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
           const V3 to = normalize(sub(point, x));
           HitRec sh;
           // camera.cpp:101-102: the light is skipped only when this ray hits nothing
-          if (!walk<MODE, true, COUNT, false>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
+          if (!walk<MODE, true, COUNT, false, RES>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
           float c = dot(to, nrm);
           if (c < 0.0f) c = 0.0f;
           float y = dot(to, ln);
@@ -556,6 +556,7 @@ struct Plan {
   LdsPlan lds{};       // staged part of the scene
   size_t lds_bytes = 0;
   unsigned max_blocks = 0;  // workgroups the chip keeps resident
+  bool resident = false;    // all nodes, all triangles and the whole stack are in LDS
 };
 
 struct PtScene {
@@ -640,6 +641,8 @@ static int make_plan(PtScene *s) {
   p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
   p.lds.stack_lds = (uint32_t)p.stack;
   p.lds.spill = nullptr;
+  p.resident = p.lds.n_nodes == s->dev.n_nodes && p.lds.n_tris == s->dev.n_tris && s->max_depth <= (uint32_t)p.stack &&
+               !std::getenv("PT_NO_RESIDENT");
   if (std::getenv("PT_VERBOSE"))
     std::fprintf(stderr, "ptgpu plan: depth %u, block %d, LDS stack %d entries/lane, %u nodes + %u triangles in LDS, %zu B LDS per workgroup, %u resident workgroups\n",
                  s->max_depth, p.block, p.stack, p.lds.n_nodes, p.lds.n_tris, p.lds_bytes, p.max_blocks);
@@ -725,7 +728,7 @@ template <int MODE, bool COUNT>
 static int launch_trace_queue(PtScene *s, const FrameDev &F, int depth, uint32_t n, const QueueDev &q, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = k_trace_queue<MODE, BLOCK, COUNT>;
+    auto k = s->plan.resident ? k_trace_queue<MODE, BLOCK, COUNT, true> : k_trace_queue<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n, q,
@@ -740,7 +743,7 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
                         const QueueDev &out, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = k_shade<MODE, BLOCK, COUNT>;
+    auto k = s->plan.resident ? k_shade<MODE, BLOCK, COUNT, true> : k_shade<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     const Workspace &w = s->ws;
