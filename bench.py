@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--others", dest="others", action="store_true", default=True,
                     help="after the main run, one short frame of each other named configuration (default)")
     ap.add_argument("--no-others", dest="others", action="store_false")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo only to rehearse the N>1 path on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses cuda:0 (rehearsal of the N>1 path on a one-GPU box, with --backend gloo)")
     return ap.parse_args()
 
 
@@ -218,10 +222,15 @@ def main():
     import torch.distributed as dist
     from pathtracer_amd import scenes
 
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     cfg = workload(args)
     res, (meshes, mats, cam_kw, opt_kw) = run_config(args.config, cfg, args.mode, args.max_depth, args.aperture,
