@@ -96,6 +96,9 @@ struct SceneDev {
   const ptl::LightTri *light_tris;
   uint32_t n_nodes, n_tris, n_lights, n_mats;
   float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
+  uint32_t quorum;      // 64ths of a wave's unfinished lanes that must hold a parked leaf before triangles are tested
+  uint32_t quorum_any;  // the same for any-hit walks, where a tested leaf may end the ray
+  uint32_t refill;  // idle lanes of a wave at which k_trace_queue retires finished rays and fetches new ones
 };
 
 struct HitRec {
@@ -234,23 +237,44 @@ __device__ __forceinline__ uint32_t pop_ref(const LdsScene &C, uint32_t stk, uin
   return C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride];
 }
 
-// Walks the tree for one ray.  MODE: PT_TRACE_EXACT reaches exactly the leaves the
+// Walks the tree for one ray per lane.  MODE: PT_TRACE_EXACT reaches exactly the leaves the
 // reference reaches; PT_TRACE_FAST additionally skips leaves and groups whose box
 // the ray misses (with slack) and subtrees that start beyond the best hit (with
 // slack), and descends near child first.  ANY: stop at the first accepted triangle.
 // `stk` is the offset (in 32-bit words of the kernel's LDS block) of this lane's stack
 // column; entries are `stride` words apart.
 //
-// Shape: one loop whose step is either a node (two child boxes) or a leaf (its triangles),
-// so every step advances every live lane.  A nested "nodes until a leaf, then the leaf"
-// shape was measured twice as slow: the wave then takes the longest node run of any lane
-// in every round, and node steps are the expensive ones.
+// Shape: the wave alternates between node steps and triangle tests, and a lane that reaches a
+// leaf does not test it at once: it parks the leaf in `pend` and goes on with the next node from
+// its stack.  The wave tests triangles only when S.quorum/64 of its unfinished lanes hold a parked
+// leaf (or when no lane has node work left), so the expensive triangle code runs with many lanes active instead
+// of the one or two that happen to be at a leaf in a given step (measured before: 42 % of the
+// lanes active per vector instruction).  A lane with a parked leaf that reaches a second one
+// waits.  Deferring a leaf only delays the tightening of the cull distance; the result does
+// not depend on the order in which leaves are tested (ties go to the larger rank).
+// All lanes leave the loop together.
 //
 // RES: the launch keeps every node, every triangle and the whole stack in LDS (small scenes);
 // the tests that choose between LDS and global memory then fall away at compile time.
-template <int MODE, bool ANY, bool COUNT, bool WANT_N = false, bool RES = false>
-__device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o, V3 d, uint32_t stk, uint32_t stride,
-                                     HitRec &best, uint32_t &n_boxes, uint32_t &n_tris) {
+// Traversal state of one lane's ray, kept across rounds so that a kernel can hand a finished
+// lane its next ray while the other lanes of the wave go on (k_trace_queue).
+struct RayState {
+  V3 o, d;
+  float ix, iy, iz;   // 1/d per axis, or the skip value for d == 0
+  V3 on, of;          // origins for the entry and exit planes (they differ only on d == 0 axes)
+  bool sx, sy, sz;    // 1/d negative
+  float cull;         // fast mode: nothing beyond this distance can win
+  uint32_t cur;       // node or leaf reference this lane handles next
+  uint32_t pend;      // parked leaf reference (leaf references have the top bit set, so 0 = none)
+  int sp;
+  bool live;          // cur is valid
+  bool found;         // ANY: a triangle was hit
+  HitRec best;
+  __device__ __forceinline__ bool done() const { return !live && pend == 0; }
+};
+
+template <int MODE, bool WANT_N>
+__device__ __forceinline__ void walk_init(const SceneDev &S, RayState &st, V3 o, V3 d) {
   // 1/d per axis as AABB::intersect forms it (object.cpp:183).  An axis with d == 0 is
   // skipped there without checking that the origin lies inside the slab; a NaN reciprocal
   // reproduces that (NaN never updates tmin/tmax).  Such a ray then passes every box on that
@@ -261,78 +285,114 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
   // the slab): node boxes touch triangle edges, and an edge a rounding error away from the
   // ray's plane can still be hit by the reference's triangle test.
   const float skip = (MODE == PT_TRACE_FAST) ? __builtin_inff() : __builtin_nanf("");
-  const float ix = d.x != 0.0f ? 1.0f / d.x : skip;
-  const float iy = d.y != 0.0f ? 1.0f / d.y : skip;
-  const float iz = d.z != 0.0f ? 1.0f / d.z : skip;
+  st.o = o;
+  st.d = d;
+  st.ix = d.x != 0.0f ? 1.0f / d.x : skip;
+  st.iy = d.y != 0.0f ? 1.0f / d.y : skip;
+  st.iz = d.z != 0.0f ? 1.0f / d.z : skip;
   const float mx = (MODE == PT_TRACE_FAST && d.x == 0.0f) ? S.margin : 0.0f;
   const float my = (MODE == PT_TRACE_FAST && d.y == 0.0f) ? S.margin : 0.0f;
   const float mz = (MODE == PT_TRACE_FAST && d.z == 0.0f) ? S.margin : 0.0f;
-  const V3 on = mk(o.x + mx, o.y + my, o.z + mz);  // origin for the entry planes
-  const V3 of = mk(o.x - mx, o.y - my, o.z - mz);  // origin for the exit planes
-  const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
-  best.t = __builtin_inff();
-  best.slot = 0xffffffffu;
-  best.rank = 0xffffffffu;
-  best.u = 0.0f;
-  best.v = 0.0f;
+  st.on = mk(o.x + mx, o.y + my, o.z + mz);
+  st.of = mk(o.x - mx, o.y - my, o.z - mz);
+  st.sx = st.ix < 0.0f;
+  st.sy = st.iy < 0.0f;
+  st.sz = st.iz < 0.0f;
+  st.best.t = __builtin_inff();
+  st.best.slot = 0xffffffffu;
+  st.best.rank = 0xffffffffu;
+  st.best.u = 0.0f;
+  st.best.v = 0.0f;
   if (WANT_N) {
-    best.n = mk(0.0f, 0.0f, 0.0f);
-    best.mat = 0u;
+    st.best.n = mk(0.0f, 0.0f, 0.0f);
+    st.best.mat = 0u;
   }
-  float cull = __builtin_inff();
-  uint32_t cur = 0;
-  int sp = 0;
-  for (;;) {
-    if (!(cur & ptl::REF_LEAF)) {
-      float4 q0, q1, q2;
-      uint4 q3;
-      if (RES || cur < C.n_nodes) {
-        const uint32_t at = C.node_base + cur;
-        q0 = lds_f4(at); q1 = lds_f4(at + C.n_nodes); q2 = lds_f4(at + 2u * C.n_nodes);
-        const float4 r = lds_f4(at + 3u * C.n_nodes);
-        q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
-      } else {
-        const size_t at = 4u * (size_t)cur;
-        q0 = glb_f4(S.nodes, at); q1 = glb_f4(S.nodes, at + 1); q2 = glb_f4(S.nodes, at + 2);
-        const float4 r = glb_f4(S.nodes, at + 3);
-        q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
-      }
-      if (COUNT) n_boxes += 2;
-      // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-      const float far = (MODE == PT_TRACE_FAST && !ANY) ? cull : __builtin_inff();
-      // both children side by side in packed pairs: (plane - origin) * (1/d), object.cpp:184-185
-      const pt_f2 ax = (pair2(sx ? q0.w : q0.x, sx ? q2.y : q1.z) - splat2(on.x)) * splat2(ix);
-      const pt_f2 bx = (pair2(sx ? q0.x : q0.w, sx ? q1.z : q2.y) - splat2(of.x)) * splat2(ix);
-      const pt_f2 ay = (pair2(sy ? q1.x : q0.y, sy ? q2.z : q1.w) - splat2(on.y)) * splat2(iy);
-      const pt_f2 by = (pair2(sy ? q0.y : q1.x, sy ? q1.w : q2.z) - splat2(of.y)) * splat2(iy);
-      const pt_f2 az = (pair2(sz ? q1.y : q0.z, sz ? q2.w : q2.x) - splat2(on.z)) * splat2(iz);
-      const pt_f2 bz = (pair2(sz ? q0.z : q1.y, sz ? q2.x : q2.w) - splat2(of.z)) * splat2(iz);
-      // tmin starts at EPSILON, tmax at the cull distance; NaN never updates (object.cpp:180,188-191)
-      const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax.x), ay.x), az.x), tf0 = fminf(fminf(fminf(far, bx.x), by.x), bz.x);
-      const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax.y), ay.y), az.y), tf1 = fminf(fminf(fminf(far, bx.y), by.y), bz.y);
-      bool p0, p1;
-      if (MODE == PT_TRACE_EXACT) {
-        // only an internal node of the reference tree is box-tested there (object.cpp:277)
-        p0 = (q3.z == KIND_INTERNAL) ? (tf0 >= tn0) : true;
-        p1 = (q3.w == KIND_INTERNAL) ? (tf1 >= tn1) : true;
-      } else {
-        // leaf and group boxes were widened by the flattener, and tf started at the cull
-        // distance, so one comparison covers the box test and the pruning
-        p0 = tf0 >= tn0;
-        p1 = tf1 >= tn1;
-      }
-      if (p0 && p1) {
-        const bool swap = (MODE == PT_TRACE_FAST && !ANY) ? (tn1 < tn0) : false;
-        push_ref<RES>(C, stk, stride, sp, swap ? q3.x : q3.y);
-        ++sp;
-        cur = swap ? q3.y : q3.x;
-        continue;
-      }
-      if (p0) { cur = q3.x; continue; }
-      if (p1) { cur = q3.y; continue; }
+  st.cull = __builtin_inff();
+  st.cur = 0;
+  st.pend = 0;
+  st.sp = 0;
+  st.live = true;
+  st.found = false;
+}
+
+// One round for the wave: a node step for every lane that has one, then — when enough lanes
+// hold a parked leaf or no lane has node work — the triangle tests of the parked leaves.
+// Lanes whose state is done() do nothing.
+template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES>
+__device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
+                                           uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris) {
+  if (st.live && !(st.cur & ptl::REF_LEAF)) {
+    float4 q0, q1, q2;
+    uint4 q3;
+    if (RES || st.cur < C.n_nodes) {
+      const uint32_t at = C.node_base + st.cur;
+      q0 = lds_f4(at); q1 = lds_f4(at + C.n_nodes); q2 = lds_f4(at + 2u * C.n_nodes);
+      const float4 r = lds_f4(at + 3u * C.n_nodes);
+      q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
     } else {
-      const uint32_t first = cur & ptl::REF_FIRST_MASK;
-      const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+      const size_t at = 4u * (size_t)st.cur;
+      q0 = glb_f4(S.nodes, at); q1 = glb_f4(S.nodes, at + 1); q2 = glb_f4(S.nodes, at + 2);
+      const float4 r = glb_f4(S.nodes, at + 3);
+      q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+    }
+    if (COUNT) n_boxes += 2;
+    // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
+    const float far = (MODE == PT_TRACE_FAST && !ANY) ? st.cull : __builtin_inff();
+    // both children side by side in packed pairs: (plane - origin) * (1/d), object.cpp:184-185
+    const pt_f2 ax = (pair2(st.sx ? q0.w : q0.x, st.sx ? q2.y : q1.z) - splat2(st.on.x)) * splat2(st.ix);
+    const pt_f2 bx = (pair2(st.sx ? q0.x : q0.w, st.sx ? q1.z : q2.y) - splat2(st.of.x)) * splat2(st.ix);
+    const pt_f2 ay = (pair2(st.sy ? q1.x : q0.y, st.sy ? q2.z : q1.w) - splat2(st.on.y)) * splat2(st.iy);
+    const pt_f2 by = (pair2(st.sy ? q0.y : q1.x, st.sy ? q1.w : q2.z) - splat2(st.of.y)) * splat2(st.iy);
+    const pt_f2 az = (pair2(st.sz ? q1.y : q0.z, st.sz ? q2.w : q2.x) - splat2(st.on.z)) * splat2(st.iz);
+    const pt_f2 bz = (pair2(st.sz ? q0.z : q1.y, st.sz ? q2.x : q2.w) - splat2(st.of.z)) * splat2(st.iz);
+    // tmin starts at EPSILON, tmax at the cull distance; NaN never updates (object.cpp:180,188-191)
+    const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax.x), ay.x), az.x), tf0 = fminf(fminf(fminf(far, bx.x), by.x), bz.x);
+    const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax.y), ay.y), az.y), tf1 = fminf(fminf(fminf(far, bx.y), by.y), bz.y);
+    bool p0, p1;
+    if (MODE == PT_TRACE_EXACT) {
+      // only an internal node of the reference tree is box-tested there (object.cpp:277)
+      p0 = (q3.z == KIND_INTERNAL) ? (tf0 >= tn0) : true;
+      p1 = (q3.w == KIND_INTERNAL) ? (tf1 >= tn1) : true;
+    } else {
+      // leaf and group boxes were widened by the flattener, and tf started at the cull
+      // distance, so one comparison covers the box test and the pruning
+      p0 = tf0 >= tn0;
+      p1 = tf1 >= tn1;
+    }
+    if (p0 && p1) {
+      const bool swap = (MODE == PT_TRACE_FAST && !ANY) ? (tn1 < tn0) : false;
+      push_ref<RES>(C, stk, stride, st.sp, swap ? q3.x : q3.y);
+      ++st.sp;
+      st.cur = swap ? q3.y : q3.x;
+    } else if (p0) {
+      st.cur = q3.x;
+    } else if (p1) {
+      st.cur = q3.y;
+    } else if (st.sp == 0) {
+      st.live = false;
+    } else {
+      --st.sp;
+      st.cur = pop_ref<RES>(C, stk, stride, st.sp);
+    }
+  }
+  if (st.live && (st.cur & ptl::REF_LEAF) && st.pend == 0) {  // park the leaf, go on with the next node
+    st.pend = st.cur;
+    if (st.sp == 0) {
+      st.live = false;
+    } else {
+      --st.sp;
+      st.cur = pop_ref<RES>(C, stk, stride, st.sp);
+    }
+  }
+  const unsigned long long m_pend = __ballot(st.pend != 0);
+  const unsigned long long m_node = __ballot(st.live && !(st.cur & ptl::REF_LEAF));
+  if (m_pend == 0) return;
+  const uint32_t unfinished = (uint32_t)__popcll(__ballot(!st.done()));
+  if ((uint32_t)__popcll(m_pend) * 64u >= (ANY ? S.quorum_any : S.quorum) * unfinished || m_node == 0) {
+    if (st.pend != 0) {
+      const uint32_t first = st.pend & ptl::REF_FIRST_MASK;
+      const uint32_t cnt = ((st.pend >> 28) & 7u) + 1u;
+      st.pend = 0;
       const bool in_lds = RES || first + cnt <= C.n_tris;
       for (uint32_t k = 0; k < cnt; k += 2) {
         // an odd last triangle is paired with itself and its second copy ignored
@@ -351,35 +411,48 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
         }
         bool h0, h1;
         pt_f2 t2, u2, v2;
-        tri_test2(a0, b0, c0, a1, b1, c1, o, d, h0, h1, t2, u2, v2);
+        tri_test2(a0, b0, c0, a1, b1, c1, st.o, st.d, h0, h1, t2, u2, v2);
         h1 = h1 && two;
         if (ANY) {
-          if (h0 || h1) return true;
+          if (h0 || h1) {
+            st.found = true;
+            st.live = false;
+            break;
+          }
         } else {
           // larger rank wins a tie: the reference's leftmost-in-leaf / right-sibling rule
-          if (h0 && (t2.x < best.t || (t2.x == best.t && (int32_t)__float_as_uint(c0.w) > (int32_t)best.rank))) {
-            best.t = t2.x; best.slot = s0; best.rank = __float_as_uint(c0.w); best.u = u2.x; best.v = v2.x;
+          if (h0 && (t2.x < st.best.t || (t2.x == st.best.t && (int32_t)__float_as_uint(c0.w) > (int32_t)st.best.rank))) {
+            st.best.t = t2.x; st.best.slot = s0; st.best.rank = __float_as_uint(c0.w); st.best.u = u2.x; st.best.v = v2.x;
             if (WANT_N) {
-              best.n = cross(mk(a0.w, b0.x, b0.y), mk(b0.z, b0.w, c0.x));  // (v1-v0) x (v2-v0), object.cpp:393
-              best.mat = __float_as_uint(c0.z);
+              st.best.n = cross(mk(a0.w, b0.x, b0.y), mk(b0.z, b0.w, c0.x));  // (v1-v0) x (v2-v0), object.cpp:393
+              st.best.mat = __float_as_uint(c0.z);
             }
           }
-          if (h1 && (t2.y < best.t || (t2.y == best.t && (int32_t)__float_as_uint(c1.w) > (int32_t)best.rank))) {
-            best.t = t2.y; best.slot = s1; best.rank = __float_as_uint(c1.w); best.u = u2.y; best.v = v2.y;
+          if (h1 && (t2.y < st.best.t || (t2.y == st.best.t && (int32_t)__float_as_uint(c1.w) > (int32_t)st.best.rank))) {
+            st.best.t = t2.y; st.best.slot = s1; st.best.rank = __float_as_uint(c1.w); st.best.u = u2.y; st.best.v = v2.y;
             if (WANT_N) {
-              best.n = cross(mk(a1.w, b1.x, b1.y), mk(b1.z, b1.w, c1.x));
-              best.mat = __float_as_uint(c1.z);
+              st.best.n = cross(mk(a1.w, b1.x, b1.y), mk(b1.z, b1.w, c1.x));
+              st.best.mat = __float_as_uint(c1.z);
             }
           }
-          if (MODE == PT_TRACE_FAST) cull = best.t + (best.t * PT_SLACK_REL + PT_SLACK_ABS);
+          if (MODE == PT_TRACE_FAST) st.cull = st.best.t + (st.best.t * PT_SLACK_REL + PT_SLACK_ABS);
         }
       }
     }
-    if (sp == 0) break;
-    --sp;
-    cur = pop_ref<RES>(C, stk, stride, sp);
   }
-  return best.slot != 0xffffffffu;
+}
+
+// The whole walk for one ray per lane; all lanes return together.
+template <int MODE, bool ANY, bool COUNT, bool WANT_N = false, bool RES = false>
+__device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o, V3 d, uint32_t stk, uint32_t stride,
+                                     HitRec &best, uint32_t &n_boxes, uint32_t &n_tris) {
+  RayState st;
+  walk_init<MODE, WANT_N>(S, st, o, d);
+  do {
+    walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris);
+  } while (__ballot(!st.done()) != 0);
+  best = st.best;
+  return ANY ? st.found : st.best.slot != 0xffffffffu;
 }
 
 }  // namespace ptd

@@ -182,49 +182,109 @@ __device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 }
 
+// Does the path of queue entry i go on after a vertex whose closest hit is at t?  It does iff it
+// hit something and passes Russian roulette (camera.cpp:65, 118-119).
+__device__ __forceinline__ bool survives(const SceneDev &S, const FrameDev &F, int depth, const QueueDev &q, uint32_t i,
+                                         float t) {
+  if (t == __builtin_inff()) return false;
+  if (F.max_depth > 0 && depth >= F.max_depth) return false;
+  if (depth <= F.rr_min_depth) return true;  // the roulette draw exists only when depth > rr_min_depth
+  const uint32_t id = q.id[i];
+  PathRng rng;
+  rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
+  const uint32_t dim = 2u + (uint32_t)depth * F.dims_per_vertex + 3u * S.n_lights;
+  return (double)rng.real(0.0f, 1.0f, dim) < (double)F.rr_prob;
+}
+
 // Closest hit for every queued ray.  The kernel also decides which paths go on after this
 // vertex — a path continues iff it hit something and passes Russian roulette (camera.cpp:65,
-// 118-119) — and leaves the 64-bit mask of each chunk in chunk_mask, so that the survivors'
-// places in the next queue are known (k_scan_*) before k_shade writes them.
+// 118-119) — and leaves that as one byte per ray in `alive`, from which k_scan_local forms the
+// 64-bit mask of each chunk, so that the survivors' places in the next queue are known before
+// k_shade writes them.
+//
+// Rays differ widely in the number of steps they need, so a wave does not walk 64 rays in
+// lockstep until the slowest is done (measured: 42 % of the lanes active).  Each lane carries
+// its own ray; when S.refill lanes are idle the wave stores their results and hands them the
+// next rays of the run of chunks it has claimed, claiming another run when that one is used up.
 template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth,
-                                                       uint32_t n, QueueDev q, HitDev hit,
-                                                       unsigned long long *chunk_mask, uint32_t *head,
-                                                       unsigned long long *stats) {
+                                                       uint32_t n, QueueDev q, HitDev hit, uint8_t *alive_out,
+                                                       uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
-  const uint32_t lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0;
-  for (;;) {
-    const uint32_t run = next_run(head, kRun);
-    if ((uint64_t)run * 64u >= n) break;
-    for (uint32_t c = 0; c < kRun; ++c) {
-      const uint32_t base = (run + c) * 64u;
-      if (base >= n) break;
-      const uint32_t i = base + lane;
-      bool alive = false;
-      if (i < n) {
-        const V3 o = mk(q.ox[i], q.oy[i], q.oz[i]);
-        const V3 d = mk(q.dx[i], q.dy[i], q.dz[i]);
-        HitRec h;
-        walk<MODE, false, COUNT, true, RES>(S, C, o, d, stk, BLOCK, h, nb, nt);
-        hit.t[i] = h.t;
-        hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
-        hit.mat[i] = h.mat;
-        if (h.t != __builtin_inff()) {
-          alive = depth <= F.rr_min_depth;
-          if (!alive) {  // the roulette draw exists only when depth > rr_min_depth
-            const uint32_t id = q.id[i];
-            PathRng rng;
-            rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
-            const uint32_t dim = 2u + (uint32_t)depth * F.dims_per_vertex + 3u * S.n_lights;
-            alive = (double)rng.real(0.0f, 1.0f, dim) < (double)F.rr_prob;
-          }
-          if (F.max_depth > 0 && depth >= F.max_depth) alive = false;
+  if constexpr (RES) {
+    // Scene in LDS: walks are short and cost no memory latency, and handing out rays lane by lane
+    // was measured slower than walking whole chunks (its bookkeeping runs with few lanes active).
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+      const uint32_t run = next_run(head, kRun);
+      if ((uint64_t)run * 64u >= n) break;
+      for (uint32_t c = 0; c < kRun; ++c) {
+        const uint32_t base = (run + c) * 64u;
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+          HitRec h;
+          walk<MODE, false, COUNT, true, RES>(S, C, mk(q.ox[i], q.oy[i], q.oz[i]), mk(q.dx[i], q.dy[i], q.dz[i]), stk, BLOCK,
+                                              h, nb, nt);
+          hit.t[i] = h.t;
+          hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
+          hit.mat[i] = h.mat;
+          alive_out[i] = survives(S, F, depth, q, i, h.t) ? 1 : 0;
         }
       }
-      const unsigned long long m = __ballot(alive);
-      if (lane == 0) chunk_mask[run + c] = m;
+    }
+  } else {
+    uint32_t pool = 0, pool_end = 0;  // rays of the claimed run not handed out yet (same in all lanes)
+    bool more = true;                 // the queue may hold further runs
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t mine = NONE;             // ray this lane works on or has finished
+    bool busy = false;
+    RayState st;
+    st.live = false;
+    st.pend = 0;
+    for (;;) {
+      const unsigned long long m_busy = __ballot(busy);
+      const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
+      const bool can_fetch = more || pool < pool_end;
+      if ((n_idle >= S.refill && can_fetch) || m_busy == 0) {
+        if (!busy && mine != NONE) {  // retire
+          const HitRec &h = st.best;
+          hit.t[mine] = h.t;
+          hit.nx[mine] = h.n.x; hit.ny[mine] = h.n.y; hit.nz[mine] = h.n.z;
+          hit.mat[mine] = h.mat;
+          alive_out[mine] = survives(S, F, depth, q, mine, h.t) ? 1 : 0;
+          mine = NONE;
+        }
+        if (pool >= pool_end && more) {
+          const uint32_t run = next_run(head, kRun);
+          if ((uint64_t)run * 64u >= n) {
+            more = false;
+          } else {
+            pool = run * 64u;
+            const uint64_t e = ((uint64_t)run + kRun) * 64u;
+            pool_end = e < n ? (uint32_t)e : n;
+          }
+        }
+        if (!busy) {
+          const unsigned long long idle = ~m_busy;
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+          const uint32_t i = pool + rank;
+          if (i < pool_end) {
+            walk_init<MODE, true>(S, st, mk(q.ox[i], q.oy[i], q.oz[i]), mk(q.dx[i], q.dy[i], q.dz[i]));
+            mine = i;
+            busy = true;
+          }
+        }
+        pool = pool_end - pool > n_idle ? pool + n_idle : pool_end;
+        if (__ballot(busy) == 0) {
+          if (!more && pool >= pool_end) break;
+          continue;  // this run is used up: claim the next one
+        }
+      }
+      walk_round<MODE, false, COUNT, true, RES>(S, C, st, stk, BLOCK, nb, nt);
+      if (busy && st.done()) busy = false;
     }
   }
   if (COUNT) {
@@ -479,14 +539,33 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
   return wave_tot[wave] + inc - v;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_local(uint32_t n_chunks, const unsigned long long *chunk_mask,
-                                                           uint32_t *chunk_base, uint32_t *block_tot) {
+// 8 bytes that are each 0 or 1 -> 8 bits, byte k to bit k (the products land on distinct bits).
+__device__ __forceinline__ unsigned long long pack8(unsigned long long w) { return (w * 0x0102040810204080ull) >> 56; }
+
+// Also turns the per-ray survivor bytes of k_trace_queue into the 64-bit mask of each chunk.
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(uint32_t n, uint32_t n_chunks, const uint8_t *alive,
+                                                           unsigned long long *chunk_mask, uint32_t *chunk_base,
+                                                           uint32_t *block_tot) {
   __shared__ uint32_t wave_tot[65];
   const uint32_t first = (blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
   uint32_t c[kScanPer], sum = 0;
 #pragma unroll
   for (int k = 0; k < kScanPer; ++k) {
-    c[k] = first + k < n_chunks ? (uint32_t)__popcll(chunk_mask[first + k]) : 0u;
+    c[k] = 0u;
+    if (first + k < n_chunks) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(alive + (size_t)(first + k) * 64u);
+      unsigned long long m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 w = p[j];
+        m |= (pack8((unsigned long long)w.x | ((unsigned long long)w.y << 32)) |
+              (pack8((unsigned long long)w.z | ((unsigned long long)w.w << 32)) << 8)) << (16 * j);
+      }
+      const uint32_t valid = n - (first + k) * 64u;  // the last chunk may be short; its tail bytes were never written
+      if (valid < 64u) m &= (1ull << valid) - 1ull;
+      chunk_mask[first + k] = m;
+      c[k] = (uint32_t)__popcll(m);
+    }
     sum += c[k];
   }
   uint32_t total;
@@ -547,6 +626,7 @@ struct Workspace {
   unsigned long long *chunk_mask = nullptr;  // one per 64 queue entries
   uint32_t *chunk_base = nullptr;
   uint32_t *block_tot = nullptr;             // one per kScanSpan chunks, at most kScanBlock
+  uint8_t *alive = nullptr;                  // one per queue entry: the path goes on after this vertex
 };
 
 // Launch geometry of the traversal kernels for one scene.
@@ -668,7 +748,7 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   const size_t stride = (cap + 63) & ~(size_t)63;
   const size_t n_chunks = stride / 64;
   if ((n_chunks + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock) return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
-  const size_t extra = n_chunks * 12 + (size_t)kScanBlock * 4 + 256;
+  const size_t extra = n_chunks * 12 + (size_t)kScanBlock * 4 + 256 + stride;
   HIP_TRY(hipMalloc(&w.block, arrays * stride * sizeof(float) + extra));
   float *p = w.block;
   auto take = [&]() { float *r = p; p += stride; return r; };
@@ -684,6 +764,7 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   w.chunk_mask = reinterpret_cast<unsigned long long *>(p);
   w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
   w.block_tot = w.chunk_base + n_chunks;
+  w.alive = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(w.block_tot + kScanBlock) + 63) & ~(uintptr_t)63);
   w.cap = cap;
   return PT_OK;
 }
@@ -732,7 +813,7 @@ static int launch_trace_queue(PtScene *s, const FrameDev &F, int depth, uint32_t
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n, q,
-                       s->ws.hit, s->ws.chunk_mask, s->d_cnt + 2, s->d_stats);
+                       s->ws.hit, s->ws.alive, s->d_cnt + 2, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -896,6 +977,21 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.n_nodes = (uint32_t)f.nodes.size(); s->dev.n_tris = (uint32_t)f.tris.size();
   s->dev.n_lights = (uint32_t)f.lights.size(); s->dev.n_mats = (uint32_t)f.mats.size();
   s->dev.margin = f.max_abs_coord * (1.0f / 2048.0f) + 2.0e-5f;
+  s->dev.quorum = 32;
+  s->dev.quorum_any = 32;
+  if (const char *e = std::getenv("PT_QUORUM_ANY")) {  // tuning knob
+    const int q = std::atoi(e);
+    if (q >= 1 && q <= 64) s->dev.quorum_any = (uint32_t)q;
+  }
+  s->dev.refill = 16;
+  if (const char *e = std::getenv("PT_REFILL")) {  // tuning knob
+    const int r = std::atoi(e);
+    if (r >= 1 && r <= 64) s->dev.refill = (uint32_t)r;
+  }
+  if (const char *e = std::getenv("PT_QUORUM")) {  // tuning knob
+    const int q = std::atoi(e);
+    if (q >= 1 && q <= 64) s->dev.quorum = (uint32_t)q;
+  }
   s->max_depth = f.max_depth; s->n_meshes = f.n_meshes;
   return make_plan(s);
 }
@@ -1148,7 +1244,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
       else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], st);
       if (rc != PT_OK) return rc;
       const uint32_t n_chunks = (n + 63) / 64, n_sblocks = (n_chunks + kScanSpan - 1) / kScanSpan;
-      hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n_chunks, w.chunk_mask, w.chunk_base, w.block_tot);
+      hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n, n_chunks, w.alive, w.chunk_mask, w.chunk_base, w.block_tot);
       hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, s->d_cnt);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
