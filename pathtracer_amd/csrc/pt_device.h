@@ -96,8 +96,8 @@ struct SceneDev {
   const ptl::LightTri *light_tris;
   uint32_t n_nodes, n_tris, n_lights, n_mats;
   float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
-  uint32_t quorum;      // 64ths of a wave's unfinished lanes that must hold a parked leaf before triangles are tested
-  uint32_t quorum_any;  // the same for any-hit walks, where a tested leaf may end the ray
+  uint32_t quorum;      // lanes of a wave that must hold a parked leaf before triangles are tested (closest hit)
+  uint32_t quorum_any;  // any-hit walks: the same in 64ths of the wave's unfinished lanes
   uint32_t refill;  // idle lanes of a wave at which k_trace_queue retires finished rays and fetches new ones
 };
 
@@ -246,7 +246,7 @@ __device__ __forceinline__ uint32_t pop_ref(const LdsScene &C, uint32_t stk, uin
 //
 // Shape: the wave alternates between node steps and triangle tests, and a lane that reaches a
 // leaf does not test it at once: it parks the leaf in `pend` and goes on with the next node from
-// its stack.  The wave tests triangles only when S.quorum/64 of its unfinished lanes hold a parked
+// its stack.  The wave tests triangles only when enough of its lanes (S.quorum) hold a parked
 // leaf (or when no lane has node work left), so the expensive triangle code runs with many lanes active instead
 // of the one or two that happen to be at a leaf in a given step (measured before: 42 % of the
 // lanes active per vector instruction).  A lane with a parked leaf that reaches a second one
@@ -387,8 +387,12 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   const unsigned long long m_pend = __ballot(st.pend != 0);
   const unsigned long long m_node = __ballot(st.live && !(st.cur & ptl::REF_LEAF));
   if (m_pend == 0) return;
-  const uint32_t unfinished = (uint32_t)__popcll(__ballot(!st.done()));
-  if ((uint32_t)__popcll(m_pend) * 64u >= (ANY ? S.quorum_any : S.quorum) * unfinished || m_node == 0) {
+  // closest-hit walks run with (nearly) full waves: an absolute count will do; any-hit walks sit
+  // inside the light loop of the shading kernel with whatever lanes hit something
+  bool enough;
+  if (ANY) enough = (uint32_t)__popcll(m_pend) * 64u >= S.quorum_any * (uint32_t)__popcll(__ballot(!st.done()));
+  else enough = (uint32_t)__popcll(m_pend) >= S.quorum;
+  if (enough || m_node == 0) {
     if (st.pend != 0) {
       const uint32_t first = st.pend & ptl::REF_FIRST_MASK;
       const uint32_t cnt = ((st.pend >> 28) & 7u) + 1u;

@@ -182,6 +182,93 @@ __device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 }
 
+// Walks one ray per work item for items [0, n), persistent over the whole launch.
+//   fetch(i, o, d)  loads item i's ray; returns false when the item needs no walk (it then has
+//                   written whatever the item's output is);
+//   retire(i, st)   stores the result of a walked item.
+//
+// RES (scene in LDS): walks are short and cost no memory latency; a wave walks whole chunks of 64
+// items, all lanes together.  Handing out items lane by lane was measured slower there: its
+// bookkeeping runs with few lanes active.
+// Otherwise rays differ widely in the number of steps and every step waits on memory, so a wave
+// does not walk 64 rays in lockstep until the slowest is done (measured: 42 % of the lanes active).
+// Each lane carries its own ray; when S.refill lanes are idle the wave stores their results and
+// hands them the next items of the run of chunks it has claimed, claiming another run when that
+// one is used up (1.8 times the rays per second on a 260 k-triangle scene).
+template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES, int BLOCK, typename Fetch, typename Retire>
+__device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C, uint32_t stk, uint64_t n, uint32_t kRun,
+                                           uint32_t *head, uint32_t &nb, uint32_t &nt, Fetch fetch, Retire retire) {
+  if constexpr (RES) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+      const uint32_t run = next_run(head, kRun);
+      if ((uint64_t)run * 64u >= n) break;
+      for (uint32_t c = 0; c < kRun; ++c) {
+        const uint64_t base = ((uint64_t)run + c) * 64u;
+        if (base >= n) break;
+        const uint64_t i = base + lane;
+        V3 o, d;
+        if (i < n && fetch(i, o, d)) {
+          RayState st;
+          walk_init<MODE, WANT_N>(S, st, o, d);
+          do {
+            walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt);
+          } while (__ballot(!st.done()) != 0);
+          retire(i, st);
+        }
+      }
+    }
+  } else {
+    uint64_t pool = 0, pool_end = 0;  // items of the claimed run not handed out yet (same in all lanes)
+    bool more = true;                 // the queue may hold further runs
+    const uint64_t NONE = ~0ull;
+    uint64_t mine = NONE;             // item this lane works on or has finished
+    bool busy = false;
+    RayState st;
+    st.live = false;
+    st.pend = 0;
+    for (;;) {
+      const unsigned long long m_busy = __ballot(busy);
+      const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
+      const bool can_fetch = more || pool < pool_end;
+      if ((n_idle >= S.refill && can_fetch) || m_busy == 0) {
+        if (!busy && mine != NONE) {
+          retire(mine, st);
+          mine = NONE;
+        }
+        if (pool >= pool_end && more) {
+          const uint32_t run = next_run(head, kRun);
+          if ((uint64_t)run * 64u >= n) {
+            more = false;
+          } else {
+            pool = (uint64_t)run * 64u;
+            const uint64_t e = ((uint64_t)run + kRun) * 64u;
+            pool_end = e < n ? e : n;
+          }
+        }
+        if (!busy) {
+          const unsigned long long idle = ~m_busy;
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+          const uint64_t i = pool + rank;
+          V3 o, d;
+          if (i < pool_end && fetch(i, o, d)) {
+            walk_init<MODE, WANT_N>(S, st, o, d);
+            mine = i;
+            busy = true;
+          }
+        }
+        pool = pool_end - pool > n_idle ? pool + n_idle : pool_end;
+        if (__ballot(busy) == 0) {
+          if (!more && pool >= pool_end) break;
+          continue;  // nothing to walk among these items, or the run is used up: fetch again
+        }
+      }
+      walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt);
+      if (busy && st.done()) busy = false;
+    }
+  }
+}
+
 // Does the path of queue entry i go on after a vertex whose closest hit is at t?  It does iff it
 // hit something and passes Russian roulette (camera.cpp:65, 118-119).
 __device__ __forceinline__ bool survives(const SceneDev &S, const FrameDev &F, int depth, const QueueDev &q, uint32_t i,
@@ -197,15 +284,9 @@ __device__ __forceinline__ bool survives(const SceneDev &S, const FrameDev &F, i
 }
 
 // Closest hit for every queued ray.  The kernel also decides which paths go on after this
-// vertex — a path continues iff it hit something and passes Russian roulette (camera.cpp:65,
-// 118-119) — and leaves that as one byte per ray in `alive`, from which k_scan_local forms the
+// vertex and leaves that as one byte per ray in `alive_out`, from which k_scan_local forms the
 // 64-bit mask of each chunk, so that the survivors' places in the next queue are known before
-// k_shade writes them.
-//
-// Rays differ widely in the number of steps they need, so a wave does not walk 64 rays in
-// lockstep until the slowest is done (measured: 42 % of the lanes active).  Each lane carries
-// its own ray; when S.refill lanes are idle the wave stores their results and hands them the
-// next rays of the run of chunks it has claimed, claiming another run when that one is used up.
+// the shading kernel writes them.
 template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth,
                                                        uint32_t n, QueueDev q, HitDev hit, uint8_t *alive_out,
@@ -213,143 +294,99 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
-  if constexpr (RES) {
-    // Scene in LDS: walks are short and cost no memory latency, and handing out rays lane by lane
-    // was measured slower than walking whole chunks (its bookkeeping runs with few lanes active).
-    const uint32_t lane = threadIdx.x & 63;
-    for (;;) {
-      const uint32_t run = next_run(head, kRun);
-      if ((uint64_t)run * 64u >= n) break;
-      for (uint32_t c = 0; c < kRun; ++c) {
-        const uint32_t base = (run + c) * 64u;
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-          HitRec h;
-          walk<MODE, false, COUNT, true, RES>(S, C, mk(q.ox[i], q.oy[i], q.oz[i]), mk(q.dx[i], q.dy[i], q.dz[i]), stk, BLOCK,
-                                              h, nb, nt);
-          hit.t[i] = h.t;
-          hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
-          hit.mat[i] = h.mat;
-          alive_out[i] = survives(S, F, depth, q, i, h.t) ? 1 : 0;
-        }
-      }
-    }
-  } else {
-    uint32_t pool = 0, pool_end = 0;  // rays of the claimed run not handed out yet (same in all lanes)
-    bool more = true;                 // the queue may hold further runs
-    const uint32_t NONE = 0xffffffffu;
-    uint32_t mine = NONE;             // ray this lane works on or has finished
-    bool busy = false;
-    RayState st;
-    st.live = false;
-    st.pend = 0;
-    for (;;) {
-      const unsigned long long m_busy = __ballot(busy);
-      const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
-      const bool can_fetch = more || pool < pool_end;
-      if ((n_idle >= S.refill && can_fetch) || m_busy == 0) {
-        if (!busy && mine != NONE) {  // retire
-          const HitRec &h = st.best;
-          hit.t[mine] = h.t;
-          hit.nx[mine] = h.n.x; hit.ny[mine] = h.n.y; hit.nz[mine] = h.n.z;
-          hit.mat[mine] = h.mat;
-          alive_out[mine] = survives(S, F, depth, q, mine, h.t) ? 1 : 0;
-          mine = NONE;
-        }
-        if (pool >= pool_end && more) {
-          const uint32_t run = next_run(head, kRun);
-          if ((uint64_t)run * 64u >= n) {
-            more = false;
-          } else {
-            pool = run * 64u;
-            const uint64_t e = ((uint64_t)run + kRun) * 64u;
-            pool_end = e < n ? (uint32_t)e : n;
-          }
-        }
-        if (!busy) {
-          const unsigned long long idle = ~m_busy;
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-          const uint32_t i = pool + rank;
-          if (i < pool_end) {
-            walk_init<MODE, true>(S, st, mk(q.ox[i], q.oy[i], q.oz[i]), mk(q.dx[i], q.dy[i], q.dz[i]));
-            mine = i;
-            busy = true;
-          }
-        }
-        pool = pool_end - pool > n_idle ? pool + n_idle : pool_end;
-        if (__ballot(busy) == 0) {
-          if (!more && pool >= pool_end) break;
-          continue;  // this run is used up: claim the next one
-        }
-      }
-      walk_round<MODE, false, COUNT, true, RES>(S, C, st, stk, BLOCK, nb, nt);
-      if (busy && st.done()) busy = false;
-    }
-  }
+  walk_items<MODE, false, COUNT, true, RES, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(q.ox[i], q.oy[i], q.oz[i]);
+        d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) {
+        const HitRec &h = st.best;
+        hit.t[i] = h.t;
+        hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
+        hit.mat[i] = h.mat;
+        alive_out[i] = survives(S, F, depth, q, (uint32_t)i, h.t) ? 1 : 0;
+      });
   if (COUNT) {
     wave_add64(stats + 0, nb);
     wave_add64(stats + 1, nt);
   }
 }
 
-template <int MODE, int BLOCK, bool COUNT>
+template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
                                                      const float *oy, const float *oz, const float *dx,
                                                      const float *dy, const float *dz, float *t, int32_t *tri,
                                                      float *u, float *v, uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
-  const uint32_t lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0;
-  for (;;) {
-    const uint32_t run = next_run(head, kRun);
-    if ((size_t)run * 64u >= n) break;
-    for (uint32_t c = 0; c < kRun; ++c) {
-      const size_t base = (size_t)(run + c) * 64u;
-      if (base >= n) break;
-      const size_t i = base + lane;
-      if (i < n) {
-        const V3 o = mk(ox[i], oy[i], oz[i]);
-        const V3 d = mk(dx[i], dy[i], dz[i]);
-        HitRec h;
-        const bool found = walk<MODE, false, COUNT, false>(S, C, o, d, stk, BLOCK, h, nb, nt);
+  walk_items<MODE, false, COUNT, false, RES, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(ox[i], oy[i], oz[i]);
+        d = mk(dx[i], dy[i], dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) {
+        const HitRec &h = st.best;
         t[i] = h.t;
-        tri[i] = found ? (int32_t)S.tris[h.slot].tri_id : -1;
+        tri[i] = h.slot != 0xffffffffu ? (int32_t)S.tris[h.slot].tri_id : -1;
         if (u) u[i] = h.u;
         if (v) v[i] = h.v;
-      }
-    }
-  }
+      });
   if (COUNT) {
     wave_add64(stats + 0, nb);
     wave_add64(stats + 1, nt);
   }
 }
 
-template <int MODE, int BLOCK>
+template <int MODE, int BLOCK, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
                                                    const float *oy, const float *oz, const float *dx, const float *dy,
                                                    const float *dz, uint8_t *hit, uint32_t *head) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
-  const uint32_t lane = threadIdx.x & 63;
-  for (;;) {
-    const uint32_t run = next_run(head, kRun);
-    if ((size_t)run * 64u >= n) break;
-    for (uint32_t c = 0; c < kRun; ++c) {
-      const size_t base = (size_t)(run + c) * 64u;
-      if (base >= n) break;
-      const size_t i = base + lane;
-      if (i < n) {
-        HitRec h;
-        uint32_t nb = 0, nt = 0;
-        hit[i] = walk<MODE, true, false, false>(S, C, mk(ox[i], oy[i], oz[i]), mk(dx[i], dy[i], dz[i]), stk, BLOCK,
-                                                h, nb, nt)
-                     ? 1
-                     : 0;
-      }
-    }
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, true, false, false, RES, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(ox[i], oy[i], oz[i]);
+        d = mk(dx[i], dy[i], dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) { hit[i] = st.found ? 1 : 0; });
+}
+
+// Visibility rays of the split shading pipeline (scenes outside LDS): item k = l*n + i is the
+// ray from vertex i towards its sample of light l, prepared by k_shade<..., 1>.
+struct ShadowDev {
+  float *x, *y, *z;        // per vertex: hit point
+  float *tx, *ty, *tz;     // per item: direction towards the light sample
+  float *wx, *wy, *wz;     // per item: what the light adds if the ray hits anything (camera.cpp:101-114)
+  uint8_t *vis;            // per item: the ray hit something
+};
+
+template <int MODE, int BLOCK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shadow_walk(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, HitDev hit,
+                                                       ShadowDev sd, uint32_t *head, unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, true, COUNT, false, false, BLOCK>(
+      S, C, stk, (uint64_t)n * S.n_lights, kRun, head, nb, nt,
+      [&](uint64_t k, V3 &o, V3 &d) {
+        const uint32_t i = (uint32_t)(k % n);
+        if (hit.t[i] == __builtin_inff()) return false;  // no vertex, no light loop: nobody reads vis[k]
+        o = mk(sd.x[i], sd.y[i], sd.z[i]);
+        d = mk(sd.tx[k], sd.ty[k], sd.tz[k]);
+        return true;
+      },
+      [&](uint64_t k, const RayState &st) { sd.vis[k] = st.found ? 1 : 0; });
+  if (COUNT) {
+    wave_add64(stats + 2, nb);
+    wave_add64(stats + 3, nt);
   }
 }
 
@@ -377,118 +414,156 @@ __device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
   return add(add(scale(t1, lx), scale(t2, ly)), scale(n, lz));
 }
 
-// One path vertex per work item.  Which paths survive was decided by k_trace_queue
-// (chunk_mask) and prefix-summed by k_scan_*, so a survivor is written straight to its place
-// in `out`: chunk offset + its rank among the chunk's survivors (wave ballot mask + popcount).
+// One light of the direct-light loop (camera.cpp:96-115) for the vertex at x with shading normal
+// nrm: the direction `to` of the visibility ray and `w`, what the light adds to the vertex if that
+// ray hits anything (the reference adds it when the ray hits *something*, camera.cpp:101-102).
+__device__ __forceinline__ void sample_light(const SceneDev &S, PathRng &rng, uint32_t base, uint32_t l, V3 x,
+                                             V3 nrm, V3 &to, V3 &w) {
+  const float4 *lp = reinterpret_cast<const float4 *>(S.lights + l);
+  const float4 l0 = lp[0], l1 = lp[1];
+  const uint32_t first = __float_as_uint(l0.x), count = __float_as_uint(l0.y);
+  const float area_f = l0.z, inv_area_f = l0.w;
+  const V3 lke = mk(l1.x, l1.y, l1.z);
+  // Polygon::sample, object.cpp:513-523: first triangle whose running area reaches r
+  const double r = (double)rng.real(0.0f, area_f, base + 3u * l);
+  uint32_t lo = 0, hi = count - 1;  // past the end the reference is undefined; take the last
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (r <= S.light_tris[first + mid].accum) hi = mid; else lo = mid + 1;
+  }
+  const float4 *qp = reinterpret_cast<const float4 *>(S.light_tris + first + lo);
+  const float4 g0 = qp[0], g1 = qp[1], g2 = qp[2];
+  const V3 lu = mk(g0.x, g0.y, g0.z), lv = mk(g0.w, g1.x, g1.y), ln = mk(g1.z, g1.w, g2.x);
+  // Triangle::sample, object.cpp:432-442 (the point is relative to v0; v0 is not added)
+  const double s = (double)rng.real(0.0f, 1.0f, base + 3u * l + 1u);
+  const double tt = (double)rng.real(0.0f, 1.0f, base + 3u * l + 2u);
+  V3 point;
+  if (s + tt <= 1.0) point = add(scale(lu, (float)s), scale(lv, (float)tt));
+  else point = add(scale(lu, (float)(1.0 - s)), scale(lv, (float)(1.0 - tt)));
+  to = normalize(sub(point, x));
+  float c = dot(to, nrm);
+  if (c < 0.0f) c = 0.0f;
+  float y = dot(to, ln);
+  if (y < 0.0f) y = 0.0f;
+  const double nn = (double)norm(to);
+  y = (float)((double)y / (nn * nn));  // std::pow(norm, 2) in double, camera.cpp:111
+  w = scale(scale(scale(lke, c), y), inv_area_f);
+}
+
+// One path vertex per work item.  Which paths survive was decided by k_trace_queue and
+// prefix-summed by k_scan_*, so a survivor is written straight to its place in `out`: chunk
+// offset + its rank among the chunk's survivors (wave ballot mask + popcount).
 // The compaction is stable: the queue stays in pixel order and no two launches differ.
 // Claiming an output slot per wave with an atomic on one counter instead was measured at
 // 260 ms per frame on its own: a single word takes under 100 atomics per microsecond.
-// cnt[1] = paths that hit something, cnt[3] = this kernel's work-queue head.
-template <int MODE, int BLOCK, bool COUNT, bool RES>
+// cnt[1] = paths that hit something, cnt[3] / cnt[4] = this kernel's work-queue head (phase 1: cnt[4]).
+//
+// PHASE 0: the whole vertex in one kernel, visibility rays walked in place (scenes in LDS).
+// PHASE 1 / 2 (scenes outside LDS): 1 prepares the visibility rays of every vertex and light
+// (ShadowDev), k_shadow_walk walks them with per-lane refill, 2 does the rest of the vertex
+// with the answers.  The weights w are added in light order in both forms, so the sums agree
+// bit for bit.
+template <int MODE, int BLOCK, bool COUNT, bool RES, int PHASE>
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth, uint32_t n,
-                                                 QueueDev in, HitDev hit, QueueDev out,
+                                                 QueueDev in, HitDev hit, QueueDev out, ShadowDev sd,
                                                  const unsigned long long *chunk_mask, const uint32_t *chunk_base,
                                                  const uint32_t *block_off, uint32_t *cnt, float *Lr, float *Lg,
                                                  float *Lb, unsigned long long *stats) {
-  uint32_t stk;
-  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t stk = 0;
+  LdsScene C{};
+  if constexpr (PHASE == 0) C = stage_scene<BLOCK>(S, plan, stk);
   const int lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0, n_hit = 0;
-  for (uint32_t run = next_run(cnt + 3, kRun), c = 0;; ++c) {
+  uint32_t *head = cnt + (PHASE == 1 ? 4 : 3);
+  for (uint32_t run = next_run(head, kRun), c = 0;; ++c) {
     if (c == kRun) {
-      run = next_run(cnt + 3, kRun);
+      run = next_run(head, kRun);
       c = 0;
     }
     const uint32_t first_item = (run + c) * 64u;
     if ((uint64_t)(run + c) * 64u >= n) break;
     const uint32_t i = first_item + (uint32_t)lane;
     const bool active = i < n;
-    const unsigned long long m = chunk_mask[run + c];
+    const unsigned long long m = PHASE == 1 ? 0ull : chunk_mask[run + c];
     const bool cont = (m >> lane) & 1ull;  // this path goes on (decided with the closest hit)
     bool alive = false, did_hit = false;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
     uint32_t id = 0;
     if (active) {
       id = in.id[i];
-      T = mk(in.tx[i], in.ty[i], in.tz[i]);
-      L = mk(in.lx[i], in.ly[i], in.lz[i]);
       const float t = hit.t[i];
+      if (PHASE != 1) {
+        T = mk(in.tx[i], in.ty[i], in.tz[i]);
+        L = mk(in.lx[i], in.ly[i], in.lz[i]);
+      }
       if (t == __builtin_inff()) {  // camera.cpp:65-66
         L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
       } else {
         did_hit = true;
         o = mk(in.ox[i], in.oy[i], in.oz[i]);
         d = mk(in.dx[i], in.dy[i], in.dz[i]);
-        const uint32_t mat_id = hit.mat[i];
         const V3 x = add(o, scale(d, t));                               // camera.cpp:68
         V3 nrm = normalize(mk(hit.nx[i], hit.ny[i], hit.nz[i]));        // camera.cpp:69
         if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);              // camera.cpp:72-73
-        const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
-        const float4 m0 = mp[0], m1 = mp[1];
-        const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
 
         PathRng rng;
         rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
         const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
 
-        // direct light: every light at every vertex, camera.cpp:96-115
-        V3 local = mk(0, 0, 0);
-        for (uint32_t l = 0; l < S.n_lights; ++l) {
-          const float4 *lp = reinterpret_cast<const float4 *>(S.lights + l);
-          const float4 l0 = lp[0], l1 = lp[1];
-          const uint32_t first = __float_as_uint(l0.x), count = __float_as_uint(l0.y);
-          const float area_f = l0.z, inv_area_f = l0.w;
-          const V3 lke = mk(l1.x, l1.y, l1.z);
-          // Polygon::sample, object.cpp:513-523: first triangle whose running area reaches r
-          const double r = (double)rng.real(0.0f, area_f, base + 3u * l);
-          uint32_t lo = 0, hi = count - 1;  // past the end the reference is undefined; take the last
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (r <= S.light_tris[first + mid].accum) hi = mid; else lo = mid + 1;
+        if (PHASE == 1) {
+          sd.x[i] = x.x; sd.y[i] = x.y; sd.z[i] = x.z;
+          for (uint32_t l = 0; l < S.n_lights; ++l) {
+            V3 to, w;
+            sample_light(S, rng, base, l, x, nrm, to, w);
+            const size_t k = (size_t)l * n + i;
+            sd.tx[k] = to.x; sd.ty[k] = to.y; sd.tz[k] = to.z;
+            sd.wx[k] = w.x; sd.wy[k] = w.y; sd.wz[k] = w.z;
           }
-          const float4 *qp = reinterpret_cast<const float4 *>(S.light_tris + first + lo);
-          const float4 g0 = qp[0], g1 = qp[1], g2 = qp[2];
-          const V3 lu = mk(g0.x, g0.y, g0.z), lv = mk(g0.w, g1.x, g1.y), ln = mk(g1.z, g1.w, g2.x);
-          // Triangle::sample, object.cpp:432-442 (the point is relative to v0; v0 is not added)
-          const double s = (double)rng.real(0.0f, 1.0f, base + 3u * l + 1u);
-          const double tt = (double)rng.real(0.0f, 1.0f, base + 3u * l + 2u);
-          V3 point;
-          if (s + tt <= 1.0) point = add(scale(lu, (float)s), scale(lv, (float)tt));
-          else point = add(scale(lu, (float)(1.0 - s)), scale(lv, (float)(1.0 - tt)));
-          const V3 to = normalize(sub(point, x));
-          HitRec sh;
-          // camera.cpp:101-102: the light is skipped only when this ray hits nothing
-          if (!walk<MODE, true, COUNT, false, RES>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
-          float c = dot(to, nrm);
-          if (c < 0.0f) c = 0.0f;
-          float y = dot(to, ln);
-          if (y < 0.0f) y = 0.0f;
-          const double nn = (double)norm(to);
-          y = (float)((double)y / (nn * nn));  // std::pow(norm, 2) in double, camera.cpp:111
-          local = add(local, scale(scale(scale(lke, c), y), inv_area_f));
-        }
+        } else {
+          const uint32_t mat_id = hit.mat[i];
+          const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
+          const float4 m0 = mp[0], m1 = mp[1];
+          const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
+          // direct light: every light at every vertex, camera.cpp:96-115
+          V3 local = mk(0, 0, 0);
+          for (uint32_t l = 0; l < S.n_lights; ++l) {
+            if (PHASE == 0) {
+              V3 to, w;
+              sample_light(S, rng, base, l, x, nrm, to, w);
+              HitRec sh;
+              // camera.cpp:101-102: the light is skipped only when this ray hits nothing
+              if (!walk<MODE, true, COUNT, false, RES>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
+              local = add(local, w);
+            } else {
+              const size_t k = (size_t)l * n + i;
+              if (!sd.vis[k]) continue;
+              local = add(local, mk(sd.wx[k], sd.wy[k], sd.wz[k]));
+            }
+          }
 
-        // Russian roulette (camera.cpp:118-119) was drawn by k_trace_queue: `cont`
-        if (cont) local = add(local, ke);  // camera.cpp:154
-        L = add(L, mul(T, local));
-        if (cont) {
-          const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
-          const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
-          V3 w;
-          if (F.sampling == PT_SAMPLE_COSINE) {
-            w = cosine_dir(nrm, rx, ry);
-            T = divs(mul(T, kd), F.rr_prob);
-          } else {
-            w = uniform_dir(nrm, rx, ry);
-            const V3 brdf = divs(kd, F.pi_f);                                   // camera.cpp:122
-            T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+          // Russian roulette (camera.cpp:118-119) was drawn by k_trace_queue: `cont`
+          if (cont) local = add(local, ke);  // camera.cpp:154
+          L = add(L, mul(T, local));
+          if (cont) {
+            const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
+            const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
+            V3 w;
+            if (F.sampling == PT_SAMPLE_COSINE) {
+              w = cosine_dir(nrm, rx, ry);
+              T = divs(mul(T, kd), F.rr_prob);
+            } else {
+              w = uniform_dir(nrm, rx, ry);
+              const V3 brdf = divs(kd, F.pi_f);                                   // camera.cpp:122
+              T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+            }
+            o = x;  // no offset along the normal, camera.cpp:155
+            d = w;
+            alive = true;
           }
-          o = x;  // no offset along the normal, camera.cpp:155
-          d = w;
-          alive = true;
         }
       }
     }
+    if (PHASE == 1) continue;
     n_hit += (uint32_t)__popcll(__ballot(did_hit));
     if (alive) {
       const uint32_t j = block_off[(run + c) / kScanSpan] + chunk_base[run + c] +
@@ -502,8 +577,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
       Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
     }
   }
-  if (lane == 0 && n_hit) atomicAdd(&cnt[1], n_hit);
-  if (COUNT) {
+  if (PHASE != 1 && lane == 0 && n_hit) atomicAdd(&cnt[1], n_hit);
+  if (COUNT && PHASE == 0) {
     wave_add64(stats + 2, nb);
     wave_add64(stats + 3, nt);
   }
@@ -627,6 +702,9 @@ struct Workspace {
   uint32_t *chunk_base = nullptr;
   uint32_t *block_tot = nullptr;             // one per kScanSpan chunks, at most kScanBlock
   uint8_t *alive = nullptr;                  // one per queue entry: the path goes on after this vertex
+  float *shadow_block = nullptr;             // split shading only: ShadowDev arrays
+  ShadowDev sd{};
+  size_t shadow_items = 0;                   // capacity in (vertex, light) pairs
 };
 
 // Launch geometry of the traversal kernels for one scene.
@@ -652,7 +730,7 @@ struct PtScene {
   Plan plan;
   Workspace ws;
   uint32_t *d_spill = nullptr;             // traversal-stack spill area (deep trees only)
-  uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, trace head, shade head
+  uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, work-queue heads of trace, shade, shade phase 1, visibility walk
   unsigned long long *d_stats = nullptr;   // node boxes, triangle tests: closest [0,1], visibility [2,3]
   uint32_t *h_cnt = nullptr;               // pinned
   unsigned long long *h_stats = nullptr;   // pinned
@@ -737,6 +815,7 @@ static int make_plan(PtScene *s) {
 
 static void free_workspace(Workspace &w) {
   if (w.block) (void)hipFree(w.block);
+  if (w.shadow_block) (void)hipFree(w.shadow_block);
   w = Workspace();
 }
 
@@ -766,6 +845,16 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   w.block_tot = w.chunk_base + n_chunks;
   w.alive = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(w.block_tot + kScanBlock) + 63) & ~(uintptr_t)63);
   w.cap = cap;
+  if (!s->plan.resident) {  // split shading: 3 floats per vertex, 6 floats + 1 byte per (vertex, light)
+    const size_t items = stride * s->dev.n_lights;
+    HIP_TRY(hipMalloc(&w.shadow_block, (3 * stride + 6 * items) * sizeof(float) + items));
+    float *sp = w.shadow_block;
+    w.sd.x = sp; sp += stride; w.sd.y = sp; sp += stride; w.sd.z = sp; sp += stride;
+    w.sd.tx = sp; sp += items; w.sd.ty = sp; sp += items; w.sd.tz = sp; sp += items;
+    w.sd.wx = sp; sp += items; w.sd.wy = sp; sp += items; w.sd.wz = sp; sp += items;
+    w.sd.vis = reinterpret_cast<uint8_t *>(sp);
+    w.shadow_items = items;
+  }
   return PT_OK;
 }
 
@@ -824,12 +913,33 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
                         const QueueDev &out, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = s->plan.resident ? k_shade<MODE, BLOCK, COUNT, true> : k_shade<MODE, BLOCK, COUNT, false>;
-    int rc = allow_lds(k, s->plan.lds_bytes);
-    if (rc != PT_OK) return rc;
     const Workspace &w = s->ws;
-    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n,
-                       in, w.hit, out, w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+    const uint32_t kRun = run_length(s->plan, n);
+    if (s->plan.resident) {
+      auto k = k_shade<MODE, BLOCK, COUNT, true, 0>;
+      int rc = allow_lds(k, s->plan.lds_bytes);
+      if (rc != PT_OK) return rc;
+      hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, kRun, F, depth, n, in,
+                         w.hit, out, w.sd, w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+      HIP_TRY(hipGetLastError());
+      return PT_OK;
+    }
+    // scene outside LDS: prepare the visibility rays, walk them with per-lane refill, finish the vertices
+    if ((size_t)n * s->dev.n_lights > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
+    auto ka = k_shade<MODE, BLOCK, COUNT, false, 1>;
+    hipLaunchKernelGGL(ka, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
+                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+    HIP_TRY(hipGetLastError());
+    auto kw = k_shadow_walk<MODE, BLOCK, COUNT>;
+    int rc = allow_lds(kw, s->plan.lds_bytes);
+    if (rc != PT_OK) return rc;
+    const size_t items = (size_t)n * s->dev.n_lights;
+    hipLaunchKernelGGL(kw, grid_for(s->plan, items), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds,
+                       run_length(s->plan, items), n, w.hit, w.sd, s->d_cnt + 5, s->d_stats);
+    HIP_TRY(hipGetLastError());
+    auto kb = k_shade<MODE, BLOCK, COUNT, false, 2>;
+    hipLaunchKernelGGL(kb, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
+                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -839,10 +949,10 @@ template <int MODE, bool COUNT>
 static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz,
                             const float *dx, const float *dy, const float *dz, float *t, int32_t *tri, float *u,
                             float *v, hipStream_t st) {
-  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 4 * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = k_trace_api<MODE, BLOCK, COUNT>;
+    auto k = s->plan.resident ? k_trace_api<MODE, BLOCK, COUNT, true> : k_trace_api<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
@@ -855,10 +965,10 @@ static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *
 template <int MODE>
 static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
                           const float *dy, const float *dz, uint8_t *hit, hipStream_t st) {
-  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 4 * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = k_any_api<MODE, BLOCK>;
+    auto k = s->plan.resident ? k_any_api<MODE, BLOCK, true> : k_any_api<MODE, BLOCK, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
@@ -967,10 +1077,10 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(up(&s->d_mats, f.mats));
   HIP_TRY(up(&s->d_lights, f.lights));
   HIP_TRY(up(&s->d_ltris, f.light_tris));
-  HIP_TRY(hipMalloc(&s->d_cnt, 4 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&s->d_cnt, 8 * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&s->d_stats, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
-  HIP_TRY(hipHostMalloc(&s->h_cnt, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&s->h_cnt, 8 * sizeof(uint32_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc(&s->h_stats, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   s->dev.nodes = s->d_nodes; s->dev.tris = s->d_tris; s->dev.mats = s->d_mats;
   s->dev.lights = s->d_lights; s->dev.light_tris = s->d_ltris;
@@ -1209,6 +1319,12 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     batch = (uint32_t)((target + F.P - 1) / F.P);
   }
   if (batch > spp_count) batch = spp_count;
+  if (!s->plan.resident) {
+    // split shading keeps 25 bytes per (vertex, light) pair: at most 24 GB of them
+    const uint64_t per_sample = (uint64_t)F.P * s->dev.n_lights * 25ull;
+    const uint64_t fit = (24ull << 30) / (per_sample ? per_sample : 1);
+    if (batch > fit) batch = (uint32_t)fit;
+  }
   if (batch < 1) batch = 1;
   while ((uint64_t)batch * F.P > (1ull << 31) && batch > 1) batch >>= 1;
   rc = ensure_workspace(s, (size_t)batch * F.P);
@@ -1238,7 +1354,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     int cur = 0;  // q[cur] holds the live paths, q[cur ^ 1] receives the survivors
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
-      HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 4 * sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
       if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
       if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], st);
       else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], st);
