@@ -1093,7 +1093,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     const int q = std::atoi(e);
     if (q >= 1 && q <= 64) s->dev.quorum_any = (uint32_t)q;
   }
-  s->dev.refill = 16;
+  s->dev.refill = 8;
   if (const char *e = std::getenv("PT_REFILL")) {  // tuning knob
     const int r = std::atoi(e);
     if (r >= 1 && r <= 64) s->dev.refill = (uint32_t)r;
