@@ -3,10 +3,15 @@
 // structure-of-arrays queue of live paths; one lane carries one ray.
 //
 //   k_raygen        Camera::point_towards (camera.cpp:161-169) [+ thin lens]  -> path queue
-//   k_trace_queue   Scene::castray (scene.cpp:18-20) for every queued ray     -> hit buffer
-//   k_shade         the body of Camera::pathtrace (camera.cpp:63-159) for one path vertex:
-//                   normal, the light loop with its visibility rays, Russian roulette, the
-//                   next direction, throughput update, and compaction of the survivors
+//   k_trace_queue   Scene::castray (scene.cpp:18-20) for every queued ray     -> hit buffer,
+//                   plus the roulette draw: one byte per ray, "this path goes on"
+//   k_scan_*        those bytes -> 64-bit chunk masks -> every survivor's place in the next queue
+//   k_shade<..,0>   the body of Camera::pathtrace (camera.cpp:63-159) for one path vertex:
+//                   normal, the light loop with its visibility rays, the next direction,
+//                   throughput update, survivors written straight to their places
+//   k_shade<..,1>, k_shadow_walk, k_shade<..,2>
+//                   the same vertex in three kernels for scenes that do not fit LDS: visibility
+//                   rays prepared, walked with per-lane refill, vertex finished
 //   k_resolve       adds the finished samples of a batch to the caller's accumulator
 //   k_trace_api / k_any_api   Seam A for callers that bring their own rays
 #include <hip/hip_runtime.h>
