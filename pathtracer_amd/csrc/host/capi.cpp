@@ -35,6 +35,31 @@ void *pth_scene_from_obj(const char *path) {
   return h;
 }
 
+// A scene read from a cache file written by pth_scene_save_cache (no parsing, no tree build).
+void *pth_scene_from_cache(const char *path) {
+  Handle *h = new (std::nothrow) Handle();
+  if (!h) {
+    g_err = "out of memory";
+    return nullptr;
+  }
+  std::string err;
+  if (!Scene::load_cache(path, h->scene, &err)) {
+    g_err = err;
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+int pth_scene_save_cache(void *h, const char *path) {
+  std::string err;
+  if (!static_cast<Handle *>(h)->scene.save_cache(path, &err)) {
+    g_err = err;
+    return -1;
+  }
+  return 0;
+}
+
 // meshes as concatenated arrays: vert_off[n+1], verts[3*nv], tri_off[n+1], tris[3*nt] (ids local
 // to the mesh), mesh_mat[n]; materials kd[3*m], ke[3*m]
 void *pth_scene_from_arrays(uint32_t n_meshes, const uint32_t *vert_off, const float *verts, const uint32_t *tri_off,
@@ -89,7 +114,10 @@ uint32_t pth_scene_lights(void *h, uint32_t *out, uint32_t cap) {
   return (uint32_t)l.size();
 }
 
-double pth_mesh_area(void *h, uint32_t mesh) { return static_cast<Handle *>(h)->scene.meshes[mesh].area(); }
+double pth_mesh_area(void *h, uint32_t mesh) {
+  const Scene &sc = static_cast<Handle *>(h)->scene;
+  return mesh < sc.desc().n_meshes ? sc.mesh_area(mesh) : 0.0;
+}
 
 // Uploads (once per device) and returns the PtScene of include/ptgpu.h, owned by the handle.
 PtScene *pth_scene_device(void *h, int device) {

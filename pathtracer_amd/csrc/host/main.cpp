@@ -18,7 +18,8 @@ static void usage(const char *argv0) {
   std::fprintf(stderr,
                "usage: %s scene.obj [-o out.ppm] [--spp N] [--width W] [--height H] [--vw A --vh B]\n"
                "          [--origin x,y,z] [--euler a,b,c] [--fov deg] [--aperture r --focus d]\n"
-               "          [--max-depth k] [--cosine] [--exact] [--seed s] [--device i] [--progress]\n",
+               "          [--max-depth k] [--cosine] [--exact] [--seed s] [--device i] [--progress]\n"
+               "          [--save-cache scene.ptscene]   (a .ptscene file is also accepted as the scene)\n",
                argv0);
 }
 
@@ -40,7 +41,7 @@ int main(int argc, char **argv) {
     usage(argv[0]);
     return 2;
   }
-  std::string scene_path = argv[1], out_path = "out.ppm";
+  std::string scene_path = argv[1], out_path = "out.ppm", cache_out;
   int spp = 16;
   bool progress = false, display = false;
   Camera cam(vec(0, 0, 0));
@@ -68,21 +69,35 @@ int main(int argc, char **argv) {
     else if (a == "--cosine") cam.options.sampling = PT_SAMPLE_COSINE;
     else if (a == "--exact") cam.options.trace_mode = PT_TRACE_EXACT;
     else if (a == "--progress") progress = true;
+    else if (a == "--save-cache") cache_out = need("--save-cache");
     else if (a == "--display") display = true;
     else if (a == "--origin") { if (!parse3(need("--origin"), cam.origin)) { usage(argv[0]); return 2; } }
     else if (a == "--euler") { if (!parse3(need("--euler"), cam.direction)) { usage(argv[0]); return 2; } }
     else { usage(argv[0]); return 2; }
   }
   pt::verbose = true;
-  ParsedScene parsed;
-  std::string err;
-  if (!parseobj(scene_path, parsed, err)) {
-    std::fprintf(stderr, "%s\n", err.c_str());
-    return 1;
-  }
   try {
-    Scene scene(std::move(parsed));
-    std::printf("%zu meshes, %zu triangles, %zu lights\n", scene.meshes.size(), scene.triangle_count(), scene.lights().size());
+    Scene scene;
+    std::string err;
+    const bool is_cache = scene_path.size() > 8 && scene_path.compare(scene_path.size() - 8, 8, ".ptscene") == 0;
+    if (is_cache) {
+      if (!Scene::load_cache(scene_path, scene, &err)) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+      }
+    } else {
+      ParsedScene parsed;
+      if (!parseobj(scene_path, parsed, err)) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+      }
+      scene = Scene(std::move(parsed));
+    }
+    if (!cache_out.empty() && !scene.save_cache(cache_out, &err)) {
+      std::fprintf(stderr, "%s\n", err.c_str());
+      return 1;
+    }
+    std::printf("%u meshes, %zu triangles, %zu lights\n", scene.desc().n_meshes, scene.triangle_count(), scene.lights().size());
     const auto t0 = std::chrono::steady_clock::now();
     int pass = 0;
     if (progress)

@@ -1,6 +1,9 @@
 // scene.cpp — host-side Scene.
 #include "scene.h"
 
+#include <cmath>
+#include <cstdio>
+#include <cstring>
 #include <stdexcept>
 
 namespace pt {
@@ -20,6 +23,17 @@ Scene &Scene::operator=(Scene &&o) noexcept {
     materials = std::move(o.materials);
     objects = std::move(o.objects);
     desc_ready_ = false;  // pointers in desc_ refer to the vectors below; rebuild lazily
+    cached_ = o.cached_;
+    if (cached_) {  // no meshes to rebuild from: take the arrays themselves
+      blas_node_offset_ = std::move(o.blas_node_offset_);
+      tri_offset_ = std::move(o.tri_offset_);
+      blas_order_ = std::move(o.blas_order_);
+      mesh_material_ = std::move(o.mesh_material_);
+      blas_nodes_ = std::move(o.blas_nodes_);
+      tri_verts_ = std::move(o.tri_verts_);
+      mats_ = std::move(o.mats_);
+      point_desc();
+    }
     dev_ = o.dev_;
     dev_ordinal_ = o.dev_ordinal_;
     o.dev_ = nullptr;
@@ -34,18 +48,53 @@ Scene::~Scene() {
 
 std::vector<int> Scene::lights() const {
   std::vector<int> res;
-  for (uint32_t id : objects.objects)
-    if (materials[meshes[id].material].emission != vec(0, 0, 0)) res.push_back((int)id);
+  for (uint32_t id : objects.objects) {
+    const int mat = cached_ ? (int)mesh_material_[id] : meshes[id].material;
+    if (materials[mat].emission != vec(0, 0, 0)) res.push_back((int)id);
+  }
   return res;
 }
 
 size_t Scene::triangle_count() const {
+  if (cached_) return tri_offset_.empty() ? 0 : tri_offset_.back();
   size_t n = 0;
   for (const Polygon &m : meshes) n += m.triangles.size();
   return n;
 }
 
+double Scene::mesh_area(size_t mesh) const {
+  if (!cached_) return meshes[mesh].area();
+  double area = 0;
+  for (uint32_t t = tri_offset_[mesh]; t < tri_offset_[mesh + 1]; ++t) {
+    const float *a = &tri_verts_[(size_t)t * 9], *b = a + 3, *c = a + 6;
+    area += (double)(std::abs(a[0] * (b[1] - c[1]) + b[0] * (c[1] - a[1]) + c[0] * (a[1] - b[1])) / 2);  // as Polygon::triangle_area
+  }
+  return area;
+}
+
+void Scene::point_desc() const {
+  const size_t nm = mesh_material_.size();
+  desc_.n_meshes = (uint32_t)nm;
+  desc_.n_tris = tri_offset_[nm];
+  desc_.n_materials = (uint32_t)mats_.size();
+  desc_.n_tlas_nodes = (uint32_t)objects.nodes.size();
+  desc_.tlas_nodes = objects.nodes.data();
+  desc_.tlas_order = objects.objects.data();
+  desc_.blas_node_offset = blas_node_offset_.data();
+  desc_.blas_nodes = blas_nodes_.data();
+  desc_.tri_offset = tri_offset_.data();
+  desc_.blas_order = blas_order_.data();
+  desc_.tri_verts = tri_verts_.data();
+  desc_.mesh_material = mesh_material_.data();
+  desc_.materials = mats_.data();
+  desc_ready_ = true;
+}
+
 void Scene::build_desc() const {
+  if (cached_) {
+    point_desc();
+    return;
+  }
   const size_t nm = meshes.size();
   blas_node_offset_.assign(nm + 1, 0);
   tri_offset_.assign(nm + 1, 0);
@@ -77,20 +126,7 @@ void Scene::build_desc() const {
     mats_[i].kd[0] = materials[i].diffuse.x; mats_[i].kd[1] = materials[i].diffuse.y; mats_[i].kd[2] = materials[i].diffuse.z;
     mats_[i].ke[0] = materials[i].emission.x; mats_[i].ke[1] = materials[i].emission.y; mats_[i].ke[2] = materials[i].emission.z;
   }
-  desc_.n_meshes = (uint32_t)nm;
-  desc_.n_tris = tri_offset_[nm];
-  desc_.n_materials = (uint32_t)mats_.size();
-  desc_.n_tlas_nodes = (uint32_t)objects.nodes.size();
-  desc_.tlas_nodes = objects.nodes.data();
-  desc_.tlas_order = objects.objects.data();
-  desc_.blas_node_offset = blas_node_offset_.data();
-  desc_.blas_nodes = blas_nodes_.data();
-  desc_.tri_offset = tri_offset_.data();
-  desc_.blas_order = blas_order_.data();
-  desc_.tri_verts = tri_verts_.data();
-  desc_.mesh_material = mesh_material_.data();
-  desc_.materials = mats_.data();
-  desc_ready_ = true;
+  point_desc();
 }
 
 const PtSceneDesc &Scene::desc() const {
@@ -129,7 +165,7 @@ void Scene::castrays(size_t n, const vec *origin, const vec *direction, HitData 
     h.t = t[i];
     if (tri[i] >= 0) {
       // global triangle id -> (mesh, local triangle)
-      size_t lo = 0, hi = meshes.size();
+      size_t lo = 0, hi = mesh_material_.size();
       while (hi - lo > 1) {
         size_t mid = (lo + hi) / 2;
         if (tri_offset_[mid] <= (uint32_t)tri[i]) lo = mid; else hi = mid;
@@ -146,6 +182,119 @@ HitData Scene::castray(vec origin, vec direction) const {
   HitData h;
   castrays(1, &origin, &direction, &h, PT_TRACE_EXACT);
   return h;
+}
+
+// ---------------------------------------------------------------- cache file
+// Layout (little endian): magic "PTSCENE1", seven uint32 counts (meshes, triangles, materials,
+// top-level nodes, mesh nodes, sizeof(PtNode), sizeof(PtMaterial)), a 64-bit FNV-1a hash of the
+// payload, then the payload: the arrays of PtSceneDesc in declaration order.
+namespace {
+
+const char kMagic[8] = {'P', 'T', 'S', 'C', 'E', 'N', 'E', '1'};
+
+struct Fnv {
+  uint64_t h = 1469598103934665603ull;
+  void add(const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  }
+};
+
+bool set_err(std::string *err, const std::string &msg) {
+  if (err) *err = msg;
+  return false;
+}
+
+}  // namespace
+
+bool Scene::save_cache(const std::string &path, std::string *err) const {
+  const PtSceneDesc &d = desc();
+  const uint32_t n_blas = d.blas_node_offset[d.n_meshes];
+  const uint32_t head[7] = {d.n_meshes, d.n_tris, d.n_materials, d.n_tlas_nodes, n_blas, (uint32_t)sizeof(PtNode),
+                            (uint32_t)sizeof(PtMaterial)};
+  struct Part { const void *p; size_t n; };
+  const Part parts[] = {
+      {d.tlas_nodes, (size_t)d.n_tlas_nodes * sizeof(PtNode)},
+      {d.tlas_order, (size_t)d.n_meshes * 4},
+      {d.blas_node_offset, ((size_t)d.n_meshes + 1) * 4},
+      {d.blas_nodes, (size_t)n_blas * sizeof(PtNode)},
+      {d.tri_offset, ((size_t)d.n_meshes + 1) * 4},
+      {d.blas_order, (size_t)d.n_tris * 4},
+      {d.tri_verts, (size_t)d.n_tris * 36},
+      {d.mesh_material, (size_t)d.n_meshes * 4},
+      {d.materials, (size_t)d.n_materials * sizeof(PtMaterial)},
+  };
+  Fnv f;
+  for (const Part &q : parts) f.add(q.p, q.n);
+  FILE *fp = std::fopen(path.c_str(), "wb");
+  if (!fp) return set_err(err, "cannot open " + path + " for writing");
+  bool ok = std::fwrite(kMagic, 1, 8, fp) == 8 && std::fwrite(head, 4, 7, fp) == 7 && std::fwrite(&f.h, 8, 1, fp) == 1;
+  for (const Part &q : parts) ok = ok && (q.n == 0 || std::fwrite(q.p, 1, q.n, fp) == q.n);
+  ok = (std::fclose(fp) == 0) && ok;
+  if (!ok) return set_err(err, "short write to " + path);
+  return true;
+}
+
+bool Scene::load_cache(const std::string &path, Scene &out, std::string *err) {
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) return set_err(err, "cannot open " + path);
+  char magic[8];
+  uint32_t head[7];
+  uint64_t want = 0;
+  bool ok = std::fread(magic, 1, 8, fp) == 8 && std::fread(head, 4, 7, fp) == 7 && std::fread(&want, 8, 1, fp) == 1;
+  if (!ok || std::memcmp(magic, kMagic, 8) != 0 || head[5] != sizeof(PtNode) || head[6] != sizeof(PtMaterial)) {
+    std::fclose(fp);
+    return set_err(err, path + " is not a scene cache of this version");
+  }
+  const uint32_t nm = head[0], nt = head[1], nmat = head[2], ntl = head[3], nbl = head[4];
+  // the counts must account for the file's size exactly before anything is allocated from them
+  const uint64_t payload = (uint64_t)ntl * sizeof(PtNode) + (uint64_t)nm * 4 + ((uint64_t)nm + 1) * 4 +
+                           (uint64_t)nbl * sizeof(PtNode) + ((uint64_t)nm + 1) * 4 + (uint64_t)nt * 4 +
+                           (uint64_t)nt * 36 + (uint64_t)nm * 4 + (uint64_t)nmat * sizeof(PtMaterial);
+  std::fseek(fp, 0, SEEK_END);
+  const long size = std::ftell(fp);
+  std::fseek(fp, 8 + 28 + 8, SEEK_SET);
+  if (size < 0 || (uint64_t)size != 8 + 28 + 8 + payload || nm == 0) {
+    std::fclose(fp);
+    return set_err(err, path + ": size does not match its header");
+  }
+  Scene s;
+  s.cached_ = true;
+  s.objects.nodes.resize(ntl);
+  s.objects.objects.resize(nm);
+  s.blas_node_offset_.resize((size_t)nm + 1);
+  s.blas_nodes_.resize(nbl);
+  s.tri_offset_.resize((size_t)nm + 1);
+  s.blas_order_.resize(nt);
+  s.tri_verts_.resize((size_t)nt * 9);
+  s.mesh_material_.resize(nm);
+  s.mats_.resize(nmat);
+  struct Part { void *p; size_t n; };
+  const Part parts[] = {
+      {s.objects.nodes.data(), (size_t)ntl * sizeof(PtNode)}, {s.objects.objects.data(), (size_t)nm * 4},
+      {s.blas_node_offset_.data(), ((size_t)nm + 1) * 4},     {s.blas_nodes_.data(), (size_t)nbl * sizeof(PtNode)},
+      {s.tri_offset_.data(), ((size_t)nm + 1) * 4},           {s.blas_order_.data(), (size_t)nt * 4},
+      {s.tri_verts_.data(), (size_t)nt * 36},                 {s.mesh_material_.data(), (size_t)nm * 4},
+      {s.mats_.data(), (size_t)nmat * sizeof(PtMaterial)},
+  };
+  Fnv f;
+  for (const Part &q : parts) {
+    ok = ok && (q.n == 0 || std::fread(q.p, 1, q.n, fp) == q.n);
+    if (ok) f.add(q.p, q.n);
+  }
+  std::fclose(fp);
+  if (!ok) return set_err(err, "short read from " + path);
+  if (f.h != want) return set_err(err, path + ": checksum mismatch");
+  if (s.tri_offset_[nm] != nt || s.blas_node_offset_[nm] != nbl) return set_err(err, path + ": offsets do not end at the totals");
+  for (uint32_t i = 0; i < nm; ++i)
+    if (s.mesh_material_[i] >= nmat) return set_err(err, path + ": material index out of range");
+  s.materials.resize(nmat);
+  for (uint32_t i = 0; i < nmat; ++i) {
+    s.materials[i].diffuse = vec(s.mats_[i].kd[0], s.mats_[i].kd[1], s.mats_[i].kd[2]);
+    s.materials[i].emission = vec(s.mats_[i].ke[0], s.mats_[i].ke[1], s.mats_[i].ke[2]);
+  }
+  out = std::move(s);  // the tree structure itself is validated by pt_scene_upload
+  return true;
 }
 
 }  // namespace pt

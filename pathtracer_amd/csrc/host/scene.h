@@ -36,6 +36,17 @@ class Scene {
   std::vector<int> lights() const;
 
   size_t triangle_count() const;
+  // Polygon::area of mesh `mesh` (object.cpp:493-495,511); from the stored vertices for a cached scene.
+  double mesh_area(size_t mesh) const;
+
+  // Binary cache of the *built* scene (both trees, their permutations, vertices, materials):
+  // loading it skips OBJ parsing and BVH construction, which dominate start-up for scenes of
+  // millions of triangles, and uploads exactly what a fresh build would upload.  A loaded
+  // scene has no `meshes` (vertex sharing is not stored); ray queries, lights(),
+  // triangle_count() and rendering work as usual.  Both return false and fill `err`.
+  bool save_cache(const std::string &path, std::string *err = nullptr) const;
+  static bool load_cache(const std::string &path, Scene &out, std::string *err = nullptr);
+  bool from_cache() const { return cached_; }
   // Fills a PtSceneDesc whose pointers refer to storage owned by this Scene.
   const PtSceneDesc &desc() const;
   // Device copy (created on first use on `device`).
@@ -43,6 +54,8 @@ class Scene {
 
  private:
   void build_desc() const;
+  void point_desc() const;  // desc_ <- the storage vectors below
+  bool cached_ = false;  // desc_ storage was read from a cache file, not built from `meshes`
   mutable bool desc_ready_ = false;
   mutable PtSceneDesc desc_{};
   mutable std::vector<uint32_t> blas_node_offset_, tri_offset_, blas_order_, mesh_material_;

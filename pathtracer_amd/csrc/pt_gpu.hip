@@ -849,10 +849,13 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
   w.block_tot = w.chunk_base + n_chunks;
   w.alive = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(w.block_tot + kScanBlock) + 63) & ~(uintptr_t)63);
-  w.cap = cap;
   if (!s->plan.resident) {  // split shading: 3 floats per vertex, 6 floats + 1 byte per (vertex, light)
     const size_t items = stride * s->dev.n_lights;
-    HIP_TRY(hipMalloc(&w.shadow_block, (3 * stride + 6 * items) * sizeof(float) + items));
+    if (hipMalloc(&w.shadow_block, (3 * stride + 6 * items) * sizeof(float) + items) != hipSuccess) {
+      w.shadow_block = nullptr;
+      free_workspace(w);
+      return fail(PT_ERR_NOMEM, "out of device memory for the visibility-ray workspace");
+    }
     float *sp = w.shadow_block;
     w.sd.x = sp; sp += stride; w.sd.y = sp; sp += stride; w.sd.z = sp; sp += stride;
     w.sd.tx = sp; sp += items; w.sd.ty = sp; sp += items; w.sd.tz = sp; sp += items;
@@ -860,6 +863,7 @@ static int ensure_workspace(PtScene *s, size_t cap) {
     w.sd.vis = reinterpret_cast<uint8_t *>(sp);
     w.shadow_items = items;
   }
+  w.cap = cap;
   return PT_OK;
 }
 
@@ -1163,7 +1167,7 @@ static int trace_dev(PtScene *s, size_t n, const float *ox, const float *oy, con
                      const float *dy, const float *dz, float *t, int32_t *tri, float *u, float *v, int mode,
                      hipStream_t st) {
   if (n == 0) return PT_OK;
-  if (n > (size_t)0x7fffffff * kBlock) return fail(PT_ERR_INVALID, "too many rays for one call");
+  if (n > ((size_t)1 << 36)) return fail(PT_ERR_INVALID, "too many rays for one call");  // the work-queue head counts chunks of 64 in 32 bits
   if (mode == PT_TRACE_EXACT)
     return s->count_stats ? launch_trace_api<PT_TRACE_EXACT, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
                           : launch_trace_api<PT_TRACE_EXACT, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);

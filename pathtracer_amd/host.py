@@ -23,6 +23,10 @@ def lib():
         L.pth_scene_from_obj.argtypes = [C.c_char_p]
         L.pth_scene_from_arrays.restype = C.c_void_p
         L.pth_scene_from_arrays.argtypes = [C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p]
+        L.pth_scene_from_cache.restype = C.c_void_p
+        L.pth_scene_from_cache.argtypes = [C.c_char_p]
+        L.pth_scene_save_cache.restype = C.c_int
+        L.pth_scene_save_cache.argtypes = [C.c_void_p, C.c_char_p]
         L.pth_scene_free.argtypes = [C.c_void_p]
         L.pth_scene_free.restype = None
         L.pth_scene_desc.restype = C.POINTER(api.PtSceneDesc)
@@ -66,6 +70,15 @@ class Scene:
     @classmethod
     def from_obj(cls, path):
         return cls(lib().pth_scene_from_obj(os.fsencode(path)))
+
+    @classmethod
+    def from_cache(cls, path):
+        """A scene saved by save_cache(): no OBJ parsing, no tree build; uploads the same arrays."""
+        return cls(lib().pth_scene_from_cache(os.fsencode(path)))
+
+    def save_cache(self, path):
+        if lib().pth_scene_save_cache(self._h, os.fsencode(path)) != 0:
+            raise OSError(lib().pth_last_error().decode())
 
     @classmethod
     def from_meshes(cls, meshes, materials):

@@ -181,3 +181,22 @@ def test_lds_resident_and_split_pipelines_agree(api, mode, monkeypatch):
         assert (util.bits(hit_a[key]) == util.bits(hit_b[key])).all()
     assert (hit_a["tri"] == hit_b["tri"]).all()
     assert (np.asarray(any_a) == np.asarray(any_b)).all()
+
+
+def test_cached_scene_renders_identically(api, tmp_path):
+    """A scene loaded from its binary cache (no parse, no tree build) gives the same image, bit for
+    bit, and the same closest hits as the scene it was saved from."""
+    from pathtracer_amd import host, scenes
+    meshes, mats = scenes.atrium(24, 6, 16, 8)
+    s = host.Scene.from_meshes(meshes, mats)
+    p = str(tmp_path / "atrium.ptscene")
+    s.save_cache(p)
+    c = host.Scene.from_cache(p)
+    cam = api.make_camera(vw=16, vh=9)
+    a, ca = s.device_scene(0).render(cam, 128, 72, 4, seed=3)
+    b, cb = c.device_scene(0).render(cam, 128, 72, 4, seed=3)
+    assert (util.bits(a) == util.bits(b)).all()
+    assert ca.rays_closest == cb.rays_closest and ca.rays_shadow == cb.rays_shadow
+    o, d = util.random_rays(5000, 11)
+    ha, hb = s.device_scene(0).trace_closest(o, d), c.device_scene(0).trace_closest(o, d)
+    assert (ha["tri"] == hb["tri"]).all() and (util.bits(ha["t"]) == util.bits(hb["t"])).all()

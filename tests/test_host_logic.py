@@ -227,3 +227,26 @@ def test_flattener_rejects_malformed_trees():
         e["tri_verts"] = e["tri_verts"][:-1]
         ds = api.DeviceScene(e)
     assert ds is None
+
+
+def test_scene_cache_round_trip_and_rejection(tmp_path):
+    """The binary cache of a built scene gives back every array of the PtSceneDesc bit for bit
+    (so the device gets exactly what a fresh parse + build uploads), and a damaged or truncated
+    file is refused instead of being uploaded."""
+    from pathtracer_amd import host, scenes
+    meshes, mats = scenes.terrain_lights(24, 5)
+    s = host.Scene.from_meshes(meshes, mats)
+    p = str(tmp_path / "scene.ptscene")
+    s.save_cache(p)
+    a, b = s.export(), host.Scene.from_cache(p).export()
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes(), k
+    raw = bytearray(open(p, "rb").read())
+    for damage in (lambda r: r[:len(r) // 2], lambda r: r[:60] + bytes([r[60] ^ 0x10]) + r[61:], lambda r: b"NOTSCENE" + r[8:],
+                   lambda r: r + b"\0"):
+        open(p, "wb").write(bytes(damage(bytes(raw))))
+        with pytest.raises(ValueError):
+            host.Scene.from_cache(p)
+    with pytest.raises(ValueError):
+        host.Scene.from_cache(str(tmp_path / "missing.ptscene"))
