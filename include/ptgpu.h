@@ -187,6 +187,17 @@ int pt_trace_closest_dev(PtScene *scene, size_t n,
                          float *t, int32_t *tri, float *u, float *v, int mode,
                          void *stream);
 
+/* HitData::hits of Scene::castray for each ray (object.cpp:203, incremented at
+ * object.cpp:281-282; the reference keeps it "for special visualizations",
+ * i.e. a heat map of how deep the tree was descended): for a hit, the number
+ * of internal nodes between the root and the winning triangle's leaf; for a
+ * miss, the length of the chain of right children whose boxes the ray passes.
+ * Host pointers. */
+int pt_trace_hits(PtScene *scene, size_t n,
+                  const float *ox, const float *oy, const float *oz,
+                  const float *dx, const float *dy, const float *dz,
+                  int32_t *hits, int mode);
+
 /* Visibility form of Seam A as camera.cpp:101 uses it:
  * hit[i] = (Scene::castray(o,d).t != INF).  Host pointers. */
 int pt_trace_any(PtScene *scene, size_t n,

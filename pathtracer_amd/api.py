@@ -71,7 +71,7 @@ EXPORTS = [
     "pt_last_error", "pt_device_count", "pt_options_default", "pt_camera_default", "pt_scene_upload",
     "pt_scene_free", "pt_scene_info", "pt_scene_count_stats", "pt_scene_read_stats", "pt_scene_profile",
     "pt_scene_read_profile", "pt_trace_closest",
-    "pt_trace_closest_dev", "pt_trace_any", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
+    "pt_trace_closest_dev", "pt_trace_any", "pt_trace_hits", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
     "pt_philox4x32",
 ]
 
@@ -105,6 +105,7 @@ def lib():
         L.pt_trace_closest.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 10 + [C.c_int]
         L.pt_trace_closest_dev.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
         L.pt_trace_any.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.c_int]
+        L.pt_trace_hits.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.c_int]
         L.pt_camera_rays.argtypes = [C.POINTER(PtCamera), C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(PtCamera), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                 C.c_uint64, C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtCounters)]
@@ -277,6 +278,14 @@ class DeviceScene:
         v = np.empty(n, np.float32)
         _check(lib().pt_trace_closest(self._h, n, *[_p(c) for c in cols], _p(t), _p(tri), _p(u), _p(v), mode))
         return dict(t=t, tri=tri, u=u, v=v)
+
+    def trace_hits(self, o, d, mode=PT_TRACE_FAST):
+        """HitData::hits of Scene::castray for each ray (object.cpp:203,281-282)."""
+        cols = self._cols(o, d)
+        n = len(cols[0])
+        hits = np.empty(n, np.int32)
+        _check(lib().pt_trace_hits(self._h, n, *[_p(c) for c in cols], _p(hits), mode))
+        return hits
 
     def trace_any(self, o, d, mode=PT_TRACE_FAST):
         cols = self._cols(o, d)

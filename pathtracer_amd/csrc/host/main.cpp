@@ -19,7 +19,8 @@ static void usage(const char *argv0) {
                "usage: %s scene.obj [-o out.ppm] [--spp N] [--width W] [--height H] [--vw A --vh B]\n"
                "          [--origin x,y,z] [--euler a,b,c] [--fov deg] [--aperture r --focus d]\n"
                "          [--max-depth k] [--cosine] [--exact] [--seed s] [--device i] [--progress]\n"
-               "          [--save-cache scene.ptscene]   (a .ptscene file is also accepted as the scene)\n",
+               "          [--save-cache scene.ptscene]   (a .ptscene file is also accepted as the scene)\n"
+               "          [--heatmap]   (instead of rendering: HitData::hits of every primary ray as a grey image)\n",
                argv0);
 }
 
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
     return 2;
   }
   std::string scene_path = argv[1], out_path = "out.ppm", cache_out;
+  bool heatmap = false;
   int spp = 16;
   bool progress = false, display = false;
   Camera cam(vec(0, 0, 0));
@@ -70,6 +72,7 @@ int main(int argc, char **argv) {
     else if (a == "--exact") cam.options.trace_mode = PT_TRACE_EXACT;
     else if (a == "--progress") progress = true;
     else if (a == "--save-cache") cache_out = need("--save-cache");
+    else if (a == "--heatmap") heatmap = true;
     else if (a == "--display") display = true;
     else if (a == "--origin") { if (!parse3(need("--origin"), cam.origin)) { usage(argv[0]); return 2; } }
     else if (a == "--euler") { if (!parse3(need("--euler"), cam.direction)) { usage(argv[0]); return 2; } }
@@ -98,6 +101,30 @@ int main(int argc, char **argv) {
       return 1;
     }
     std::printf("%u meshes, %zu triangles, %zu lights\n", scene.desc().n_meshes, scene.triangle_count(), scene.lights().size());
+    if (heatmap) {
+      // the reference keeps HitData::hits "for special visualizations" (object.cpp:203): how many
+      // internal nodes lie above what each primary ray found
+      const size_t n = (size_t)cam.OUTW * cam.OUTH;
+      std::vector<float> col(6 * n);
+      for (int y = 0; y < cam.OUTH; ++y)
+        for (int x = 0; x < cam.OUTW; ++x) {
+          const size_t i = (size_t)y * cam.OUTW + x;
+          const vec d = cam.point_towards(x, y);
+          col[i] = cam.origin.x; col[n + i] = cam.origin.y; col[2 * n + i] = cam.origin.z;
+          col[3 * n + i] = d.x; col[4 * n + i] = d.y; col[5 * n + i] = d.z;
+        }
+      std::vector<int32_t> hits(n);
+      if (pt_trace_hits(scene.device_scene(cam.device), n, &col[0], &col[n], &col[2 * n], &col[3 * n], &col[4 * n],
+                        &col[5 * n], hits.data(), cam.options.trace_mode) != PT_OK)
+        throw std::runtime_error(std::string("pt_trace_hits: ") + pt_last_error());
+      int32_t mx = 1;
+      for (int32_t h : hits) mx = std::max(mx, h);
+      std::ofstream ofs(out_path, std::ios::binary);
+      ofs << "P5\n" << cam.OUTW << " " << cam.OUTH << "\n255\n";
+      for (int32_t h : hits) ofs.put((char)(unsigned char)(h * 255 / mx));
+      std::printf("hits: max %d, written to %s\n", mx, out_path.c_str());
+      return 0;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     int pass = 0;
     if (progress)

@@ -17,6 +17,7 @@ namespace ptd {
 using ptl::KIND_GROUP;
 using ptl::KIND_INTERNAL;
 using ptl::KIND_LEAF;
+using ptl::KIND_SPLIT;
 
 struct V3 {
   float x, y, z;

@@ -93,6 +93,7 @@ struct Flattener {
     memset(&r, 0, sizeof(r));
     r.tri_id = 0xffffffffu;
     out.tris.push_back(r);
+    out.tri_levels.push_back(0);
     e.ref = REF_LEAF | next_slot;
     ++next_slot;
     e.kind = KIND_LEAF;
@@ -190,12 +191,12 @@ struct Flattener {
       g.hi[k] = std::max(a.hi[k], b.hi[k]);
     }
     g.ref = make_node(a, b);
-    g.kind = KIND_GROUP;
+    g.kind = KIND_SPLIT;
     g.depth = 1 + std::max(a.depth, b.depth);
     return g;
   }
 
-  void put_triangle(uint32_t mesh, uint32_t local) {
+  void put_triangle(uint32_t mesh, uint32_t local, uint32_t levels) {
     const uint32_t gid = d.tri_offset[mesh] + local;
     const float *p = d.tri_verts + (size_t)gid * 9;
     TriRec r;
@@ -210,10 +211,12 @@ struct Flattener {
     r.mat_id = d.mesh_material[mesh];
     r.rank = next_slot;
     out.tris.push_back(r);
+    out.tri_levels.push_back((uint8_t)std::min<uint32_t>(levels, 255u));
     ++next_slot;
   }
 
-  Entry mesh_node(uint32_t mesh, uint32_t local, uint32_t level) {
+  // `inner` counts the internal nodes of the reference above this node (HitData::hits, object.cpp:281-282).
+  Entry mesh_node(uint32_t mesh, uint32_t local, uint32_t level, uint32_t inner) {
     const uint32_t nb = d.blas_node_offset[mesh], ne = d.blas_node_offset[mesh + 1];
     const uint32_t ntri = d.tri_offset[mesh + 1] - d.tri_offset[mesh];
     if (level > kMaxRecursion) return fail("mesh tree deeper than 4096 levels");
@@ -231,13 +234,13 @@ struct Flattener {
         if (local_tri >= ntri) return fail("blas_order entry out of range");
         if (tri_seen[d.tri_offset[mesh] + local_tri]) return fail("triangle referenced twice");
         tri_seen[d.tri_offset[mesh] + local_tri] = 1;
-        put_triangle(mesh, local_tri);
+        put_triangle(mesh, local_tri, inner);
       }
       if (next_slot > MAX_TRI_SLOTS) return fail("more than 2^28 triangles");
       return split_leaf(first_slot, next_slot);
     }
-    Entry l = mesh_node(mesh, n.index_or_first, level + 1);
-    Entry r = mesh_node(mesh, n.index_or_first + 1, level + 1);
+    Entry l = mesh_node(mesh, n.index_or_first, level + 1, inner + 1);
+    Entry r = mesh_node(mesh, n.index_or_first + 1, level + 1, inner + 1);
     if (failed) return e;
     e.ref = make_node(l, r);
     e.kind = KIND_INTERNAL;
@@ -245,7 +248,7 @@ struct Flattener {
     return e;
   }
 
-  Entry tlas_node(uint32_t i, uint32_t level) {
+  Entry tlas_node(uint32_t i, uint32_t level, uint32_t inner) {
     if (level > kMaxRecursion) return fail("top-level tree deeper than 4096 levels");
     if (i >= d.n_tlas_nodes) return fail("top-level node index out of range");
     if (tlas_seen[i]) return fail("top-level node referenced twice");
@@ -262,13 +265,13 @@ struct Flattener {
         if (mesh_seen[mesh]) return fail("mesh referenced twice");
         mesh_seen[mesh] = 1;
         if (d.blas_node_offset[mesh + 1] <= d.blas_node_offset[mesh]) return fail("mesh without nodes");
-        es.push_back(mesh_node(mesh, 0, level + 1));
+        es.push_back(mesh_node(mesh, 0, level + 1, inner));
         if (failed) return e;
       }
       return group(es, 0, es.size());
     }
-    Entry l = tlas_node(n.index_or_first, level + 1);
-    Entry r = tlas_node(n.index_or_first + 1, level + 1);
+    Entry l = tlas_node(n.index_or_first, level + 1, inner + 1);
+    Entry r = tlas_node(n.index_or_first + 1, level + 1, inner + 1);
     if (failed) return e;
     e.ref = make_node(l, r);
     e.kind = KIND_INTERNAL;
@@ -398,7 +401,7 @@ struct Flattener {
       if (v >= 1 && v <= 8) leaf_size = (uint32_t)v;
     }
     out.tris.reserve((size_t)d.n_tris + 1);
-    Entry root = tlas_node(0, 0);
+    Entry root = tlas_node(0, 0, 0);
     if (failed) return PT_ERR_INVALID;
     if (next_slot != d.n_tris) {
       err = "tree does not reach every triangle";

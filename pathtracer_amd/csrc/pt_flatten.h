@@ -13,6 +13,7 @@ namespace ptl {
 struct FlatScene {
   std::vector<WideNode> nodes;       // node 0 is the super-root
   std::vector<TriRec> tris;          // in tie-rank order, plus one degenerate triangle at the end
+  std::vector<uint8_t> tri_levels;   // per triangle record: internal nodes of the reference between the root and its leaf
   std::vector<MatRec> mats;
   std::vector<LightRec> lights;
   std::vector<LightTri> light_tris;

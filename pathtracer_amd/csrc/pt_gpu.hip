@@ -364,6 +364,65 @@ __global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uin
       [&](uint64_t i, const RayState &st) { hit[i] = st.found ? 1 : 0; });
 }
 
+// HitData::hits (object.cpp:203, 281-282: "for special visualizations"): every internal node on
+// the way back up from the winning triangle adds one, so for a hit it is the number of internal
+// nodes of the reference between the root and the triangle's leaf (levels[slot], counted by the
+// flattener).  For a miss the recursion hands up the right child's empty result at every internal
+// node whose box the ray passes (`lhit.t < rhit.t ? lhit : rhit` with both infinite), and the
+// first mesh's result in a top-level leaf: the count is the length of that chain.
+__device__ __forceinline__ bool box_pass_exact(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, V3 d) {
+  const float nan = __builtin_nanf("");
+  const float ix = d.x != 0.0f ? 1.0f / d.x : nan, iy = d.y != 0.0f ? 1.0f / d.y : nan, iz = d.z != 0.0f ? 1.0f / d.z : nan;
+  const float ax = ((ix < 0.0f ? hx : lx) - o.x) * ix, bx = ((ix < 0.0f ? lx : hx) - o.x) * ix;
+  const float ay = ((iy < 0.0f ? hy : ly) - o.y) * iy, by = ((iy < 0.0f ? ly : hy) - o.y) * iy;
+  const float az = ((iz < 0.0f ? hz : lz) - o.z) * iz, bz = ((iz < 0.0f ? lz : hz) - o.z) * iz;
+  const float tn = fmaxf(fmaxf(fmaxf(1e-5f, ax), ay), az);
+  const float tf = fminf(fminf(fminf(__builtin_inff(), bx), by), bz);
+  return tf >= tn;  // the same planes, operations and NaN behaviour as the node step of the exact walk
+}
+
+__device__ __forceinline__ int32_t miss_chain_hits(const SceneDev &S, V3 o, V3 d) {
+  const float4 *nodes = reinterpret_cast<const float4 *>(S.nodes);
+  // node 0 is the super-root: its child 0 is the reference's root
+  float4 q0 = nodes[0], q1 = nodes[1], q2 = nodes[2], q3 = nodes[3];
+  uint32_t kind = __float_as_uint(q3.z), ref = __float_as_uint(q3.x);
+  float lx = q0.x, ly = q0.y, lz = q0.z, hx = q0.w, hy = q1.x, hz = q1.y;
+  int32_t hits = 0;
+  for (;;) {
+    if (kind == KIND_INTERNAL) {
+      if (!box_pass_exact(lx, ly, lz, hx, hy, hz, o, d)) break;
+      ++hits;
+    } else if (kind != KIND_GROUP) {
+      break;  // a leaf of the reference (whole or split): its empty result carries 0
+    }
+    const size_t at = 4u * (size_t)ref;
+    q1 = nodes[at + 1]; q2 = nodes[at + 2]; q3 = nodes[at + 3];
+    kind = __float_as_uint(q3.w); ref = __float_as_uint(q3.y);  // child 1: the right child / the first mesh
+    lx = q1.z; ly = q1.w; lz = q2.x; hx = q2.y; hy = q2.z; hz = q2.w;
+  }
+  return hits;
+}
+
+template <int MODE, int BLOCK, bool RES>
+__global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
+                                                    const float *oy, const float *oz, const float *dx, const float *dy,
+                                                    const float *dz, const uint8_t *levels, int32_t *hits,
+                                                    uint32_t *head) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, false, false, false, RES, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(ox[i], oy[i], oz[i]);
+        d = mk(dx[i], dy[i], dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) {
+        hits[i] = st.best.slot != 0xffffffffu ? (int32_t)levels[st.best.slot] : miss_chain_hits(S, st.o, st.d);
+      });
+}
+
 // Visibility rays of the split shading pipeline (scenes outside LDS): item k = l*n + i is the
 // ray from vertex i towards its sample of light l, prepared by k_shade<..., 1>.
 struct ShadowDev {
@@ -730,6 +789,7 @@ struct PtScene {
   ptl::MatRec *d_mats = nullptr;
   ptl::LightRec *d_lights = nullptr;
   ptl::LightTri *d_ltris = nullptr;
+  uint8_t *d_levels = nullptr;             // per triangle record: HitData::hits of a hit on it
   uint32_t max_depth = 0, n_meshes = 0;
   uint64_t bytes = 0;
   Plan plan;
@@ -987,6 +1047,22 @@ static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy
   });
 }
 
+template <int MODE>
+static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                           const float *dy, const float *dz, int32_t *hits, hipStream_t st) {
+  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
+  return dispatch_plan(s->plan, [&](auto BL) -> int {
+    constexpr int BLOCK = decltype(BL)::value;
+    auto k = s->plan.resident ? k_hits_api<MODE, BLOCK, true> : k_hits_api<MODE, BLOCK, false>;
+    int rc = allow_lds(k, s->plan.lds_bytes);
+    if (rc != PT_OK) return rc;
+    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
+                       dx, dy, dz, s->d_levels, hits, s->d_cnt + 2);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+  });
+}
+
 static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const PtOptions *opt, uint32_t n_lights,
                       FrameDev &F) {
   if (!cam) return fail(PT_ERR_INVALID, "null camera");
@@ -1062,6 +1138,7 @@ void pt_scene_free(PtScene *s) {
   if (s->d_mats) (void)hipFree(s->d_mats);
   if (s->d_lights) (void)hipFree(s->d_lights);
   if (s->d_ltris) (void)hipFree(s->d_ltris);
+  if (s->d_levels) (void)hipFree(s->d_levels);
   if (s->d_spill) (void)hipFree(s->d_spill);
   if (s->d_cnt) (void)hipFree(s->d_cnt);
   if (s->d_stats) (void)hipFree(s->d_stats);
@@ -1086,6 +1163,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(up(&s->d_mats, f.mats));
   HIP_TRY(up(&s->d_lights, f.lights));
   HIP_TRY(up(&s->d_ltris, f.light_tris));
+  HIP_TRY(up(&s->d_levels, f.tri_levels));
   HIP_TRY(hipMalloc(&s->d_cnt, 8 * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&s->d_stats, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
@@ -1279,6 +1357,36 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
     if (rc != PT_OK) break;
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(hit + off, dh, k, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(buf);
+  return rc;
+}
+
+int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
+                  const float *dy, const float *dz, int32_t *hits, int mode) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hits)) return fail(PT_ERR_INVALID, "null ray or result array");
+  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t chunk = (size_t)1 << 24;
+  const size_t m = n < chunk ? n : chunk;
+  if (m == 0) return PT_OK;
+  float *buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, 7 * m * sizeof(float)));
+  int rc = PT_OK;
+  for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
+    const size_t k = (n - off) < chunk ? (n - off) : chunk;
+    const float *src[6] = {ox + off, oy + off, oz + off, dx + off, dy + off, dz + off};
+    hipError_t e = hipSuccess;
+    for (int a = 0; a < 6 && e == hipSuccess; ++a) e = hipMemcpy(buf + a * m, src[a], k * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
+    int32_t *dh = reinterpret_cast<int32_t *>(buf + 6 * m);
+    rc = mode == PT_TRACE_EXACT ? launch_hits_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0)
+                                : launch_hits_api<PT_TRACE_FAST>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
+    if (rc != PT_OK) break;
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(hits + off, dh, k * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
   }
   (void)hipFree(buf);

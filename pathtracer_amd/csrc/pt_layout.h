@@ -15,7 +15,9 @@ enum : uint32_t {
   KIND_INTERNAL = 0,  // an internal node of the reference tree: its own box test decides (object.cpp:277)
   KIND_GROUP = 1,     // grouping node that does not exist in the reference (several meshes of one
                       // top-level leaf, or the super-root): the reference visits everything below it
-  KIND_LEAF = 2       // triangle leaf: the reference never box-tests a leaf (object.cpp:266-275)
+  KIND_LEAF = 2,      // triangle leaf: the reference never box-tests a leaf (object.cpp:266-275)
+  KIND_SPLIT = 3      // grouping node inside one reference leaf that was split into smaller leaves; walked like
+                      // KIND_GROUP, told apart only where the reference's leaf boundary matters (HitData::hits)
 };
 
 // Encoding of a traversal-stack entry / child reference.
