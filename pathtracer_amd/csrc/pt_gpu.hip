@@ -432,13 +432,13 @@ struct ShadowDev {
   uint8_t *vis;            // per item: the ray hit something
 };
 
-template <int MODE, int BLOCK, bool COUNT>
+template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_shadow_walk(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, HitDev hit,
                                                        ShadowDev sd, uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
-  walk_items<MODE, true, COUNT, false, false, BLOCK>(
+  walk_items<MODE, true, COUNT, false, RES, BLOCK>(
       S, C, stk, (uint64_t)n * S.n_lights, kRun, head, nb, nt,
       [&](uint64_t k, V3 &o, V3 &d) {
         const uint32_t i = (uint32_t)(k % n);
@@ -779,6 +779,7 @@ struct Plan {
   size_t lds_bytes = 0;
   unsigned max_blocks = 0;  // workgroups the chip keeps resident
   bool resident = false;    // all nodes, all triangles and the whole stack are in LDS
+  bool split = false;       // shading runs as three kernels (visibility rays walked on their own)
 };
 
 struct PtScene {
@@ -866,6 +867,8 @@ static int make_plan(PtScene *s) {
   p.lds.spill = nullptr;
   p.resident = p.lds.n_nodes == s->dev.n_nodes && p.lds.n_tris == s->dev.n_tris && s->max_depth <= (uint32_t)p.stack &&
                !std::getenv("PT_NO_RESIDENT");
+  p.split = !p.resident;
+  if (const char *e = std::getenv("PT_SPLIT")) p.split = std::atoi(e) != 0;  // tuning knob
   if (std::getenv("PT_VERBOSE"))
     std::fprintf(stderr, "ptgpu plan: depth %u, block %d, LDS stack %d entries/lane, %u nodes + %u triangles in LDS, %zu B LDS per workgroup, %u resident workgroups\n",
                  s->max_depth, p.block, p.stack, p.lds.n_nodes, p.lds.n_tris, p.lds_bytes, p.max_blocks);
@@ -909,7 +912,7 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
   w.block_tot = w.chunk_base + n_chunks;
   w.alive = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(w.block_tot + kScanBlock) + 63) & ~(uintptr_t)63);
-  if (!s->plan.resident) {  // split shading: 3 floats per vertex, 6 floats + 1 byte per (vertex, light)
+  if (s->plan.split) {  // split shading: 3 floats per vertex, 6 floats + 1 byte per (vertex, light)
     const size_t items = stride * s->dev.n_lights;
     if (hipMalloc(&w.shadow_block, (3 * stride + 6 * items) * sizeof(float) + items) != hipSuccess) {
       w.shadow_block = nullptr;
@@ -984,8 +987,8 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
     constexpr int BLOCK = decltype(BL)::value;
     const Workspace &w = s->ws;
     const uint32_t kRun = run_length(s->plan, n);
-    if (s->plan.resident) {
-      auto k = k_shade<MODE, BLOCK, COUNT, true, 0>;
+    if (!s->plan.split) {
+      auto k = s->plan.resident ? k_shade<MODE, BLOCK, COUNT, true, 0> : k_shade<MODE, BLOCK, COUNT, false, 0>;
       int rc = allow_lds(k, s->plan.lds_bytes);
       if (rc != PT_OK) return rc;
       hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, kRun, F, depth, n, in,
@@ -993,13 +996,13 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
       HIP_TRY(hipGetLastError());
       return PT_OK;
     }
-    // scene outside LDS: prepare the visibility rays, walk them with per-lane refill, finish the vertices
+    // prepare the visibility rays, walk them (with per-lane refill when the scene is outside LDS), finish the vertices
     if ((size_t)n * s->dev.n_lights > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
     auto ka = k_shade<MODE, BLOCK, COUNT, false, 1>;
     hipLaunchKernelGGL(ka, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
                        w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
     HIP_TRY(hipGetLastError());
-    auto kw = k_shadow_walk<MODE, BLOCK, COUNT>;
+    auto kw = s->plan.resident ? k_shadow_walk<MODE, BLOCK, COUNT, true> : k_shadow_walk<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(kw, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     const size_t items = (size_t)n * s->dev.n_lights;
@@ -1436,7 +1439,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     batch = (uint32_t)((target + F.P - 1) / F.P);
   }
   if (batch > spp_count) batch = spp_count;
-  if (!s->plan.resident) {
+  if (s->plan.split) {
     // split shading keeps 25 bytes per (vertex, light) pair: at most 24 GB of them
     const uint64_t per_sample = (uint64_t)F.P * s->dev.n_lights * 25ull;
     const uint64_t fit = (24ull << 30) / (per_sample ? per_sample : 1);
