@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--others", dest="others", action="store_true", default=True,
                     help="after the main run, one short frame of each other named configuration (default)")
     ap.add_argument("--no-others", dest="others", action="store_false")
+    ap.add_argument("--batch-spp", type=int, default=0, help="samples per pixel in flight together (0 = library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true",
@@ -92,7 +93,7 @@ OTHERS = {
 }
 
 
-def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank, local_rank, world, dev):
+def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank, local_rank, world, dev, batch_spp=0):
     """Builds the scene, renders `warmup` untimed and `steps` timed frames of it and returns the
     measurements (on every rank; sums and the slowest rank's time are already reduced)."""
     import torch
@@ -110,6 +111,8 @@ def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank,
     opt_kw = dict(trace_mode=api.PT_TRACE_FAST if mode == "fast" else api.PT_TRACE_EXACT)
     if max_depth >= 0:
         opt_kw["max_depth"] = max_depth
+    if batch_spp > 0:
+        opt_kw["batch_spp"] = batch_spp
     opt = api.make_options(spp_stride=world, **opt_kw)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -204,7 +207,7 @@ def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank,
         }
     ds.close()
     scene.close()
-    return res, (meshes, mats, cam_kw, {k: v for k, v in opt_kw.items() if k != "trace_mode"})
+    return res, (meshes, mats, cam_kw, {k: v for k, v in opt_kw.items() if k not in ("trace_mode", "batch_spp")})
 
 
 def main():
@@ -235,7 +238,7 @@ def main():
     cfg = workload(args)
     res, (meshes, mats, cam_kw, opt_kw) = run_config(args.config, cfg, args.mode, args.max_depth, args.aperture,
                                                      args.steps, args.warmup, not args.no_count, rank, local_rank,
-                                                     world, dev)
+                                                     world, dev, args.batch_spp)
     out = {
         "metric": "Mrays/s at 1080p" if cfg["H"] == 1080 else "Mrays/s",
         "value": res["value"], "unit": "Mrays/s",
