@@ -361,7 +361,7 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
       p1 = tf1 >= tn1;
     }
     if (p0 && p1) {
-      const bool swap = (MODE == PT_TRACE_FAST && !ANY) ? (tn1 < tn0) : false;
+      const bool swap = (MODE == PT_TRACE_FAST) ? (tn1 < tn0) : false;  // near child first (an any-hit walk ends sooner too)
       push_ref<RES>(C, stk, stride, st.sp, swap ? q3.x : q3.y);
       ++st.sp;
       st.cur = swap ? q3.y : q3.x;
