@@ -1,3 +1,4 @@
+// build: hipcc -O3 --offload-arch=gfx950 valu_rate.hip -o valu_rate
 // Issue-rate microbenchmark: scalar-per-lane v_mul_f32 / v_fma_f32 against packed v_pk_mul_f32 /
 // v_pk_fma_f32 on gfx950.  Each wave runs 8 independent chains; prints cycles per wave instruction per SIMD.
 #include <hip/hip_runtime.h>
