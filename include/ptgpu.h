@@ -55,6 +55,14 @@ typedef struct PtMaterial {
   float ke[3];
 } PtMaterial;
 
+/* A decoded diffuse texture (Material::diffuse_map, object.cpp:149; Image,
+ * object.cpp:31-142): RGB, 8 bits per channel, rows top to bottom as decoded,
+ * no padding.  Image::at(x, y) is rgb[(y*width + x)*3 ..] / 255 (object.cpp:128-134). */
+typedef struct PtTexture {
+  uint32_t width, height;
+  const uint8_t *rgb;
+} PtTexture;
+
 /*
  * A whole scene as the reference holds it after Scene::Scene (scene.cpp:15):
  * a top-level BVH over meshes (one Polygon per OBJ `o` group) and one private
@@ -77,6 +85,13 @@ typedef struct PtSceneDesc {
   const float *tri_verts;        /* [n_tris][3][3]: v0.xyz v1.xyz v2.xyz (Triangle::v0/v1/v2, object.cpp:529-540) */
   const uint32_t *mesh_material; /* [n_meshes] index into materials */
   const PtMaterial *materials;   /* [n_materials] */
+  /* Textured diffuse (camera.cpp:121-146).  All optional: with n_textures == 0 the three
+   * pointers are ignored and every material uses its kd. */
+  uint32_t n_textures;
+  const PtTexture *textures;         /* [n_textures] */
+  const int32_t *material_texture;   /* [n_materials] index into textures, -1 = none (diffuse_map == nullptr) */
+  const float *tri_uv;               /* [n_tris][3][2]: u,v of Triangle::vt0/vt1/vt2 (object.cpp:542-553); needed
+                                        when any material of the scene has a texture */
 } PtSceneDesc;
 
 typedef struct PtScene PtScene; /* opaque; owns the device copies */

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -93,13 +94,20 @@ struct Tree {
 struct Mat {  // object.cpp:144-156
   V3 kd = V3(.5f, .5f, .5f);
   V3 ke = V3(0, 0, 0);
+  int tex = -1;  // diffuse_map, object.cpp:149: index into World::textures, -1 = nullptr
+};
+struct Tex {  // Image, object.cpp:31-142, after decoding to RGB24
+  int w = 0, h = 0;
+  std::vector<uint8_t> rgb;
 };
 struct Tri {
   uint32_t a, b, c;
 };
 struct Mesh {  // Polygon, object.cpp:451-527
   std::vector<V3> verts;
+  std::vector<V3> vts;       // vtextures, object.cpp:453
   std::vector<Tri> tris;
+  std::vector<Tri> tri_vt;   // Triangle::vt per triangle (empty when the faces carry no vt index)
   int mat = -1;
   double area = 0;
   Tree blas;
@@ -108,6 +116,7 @@ struct Mesh {  // Polygon, object.cpp:451-527
 struct World {
   std::vector<Mesh> meshes;
   std::vector<Mat> mats;
+  std::vector<Tex> textures;
   Tree tlas;
   std::vector<uint32_t> lights;  // Scene::lights(), scene.cpp:22-30
   std::string error;
@@ -315,6 +324,17 @@ static bool finish_mesh(World &w, Mesh &m) {
       w.error = "face index outside its own object's vertices";
       return false;
     }
+  if (m.mat >= 0 && w.mats[m.mat].tex >= 0) {  // Triangle::vt0/vt1/vt2 assert this, object.cpp:542-553
+    if (m.tri_vt.size() != m.tris.size()) {
+      w.error = "textured object without texture coordinates";
+      return false;
+    }
+    for (const Tri &t : m.tri_vt)
+      if (t.a >= m.vts.size() || t.b >= m.vts.size() || t.c >= m.vts.size()) {
+        w.error = "vt index outside its own object's texture coordinates";
+        return false;
+      }
+  }
   std::vector<Box> tb(m.tris.size());
   for (size_t i = 0; i < m.tris.size(); ++i) {  // Triangle ctor, object.cpp:377-382
     V3 a = m.verts[m.tris[i].a], b = m.verts[m.tris[i].b], c = m.verts[m.tris[i].c];
@@ -349,7 +369,36 @@ static bool finish_world(World &w) {  // Scene::Scene, scene.cpp:15
 }
 
 // ---------------------------------------------------------------- OBJ / MTL (object.cpp:555-710)
+static std::string dir_of(const std::string &p);
+
+// The reference decodes map_Kd files with FFmpeg (object.cpp:47-121), which this image does not
+// have; binary PPM (P6, maxval 255) is what this restatement reads.
+static bool load_ppm(const std::string &path, Tex &t) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return false;
+  std::string magic;
+  in >> magic;
+  if (magic != "P6") return false;
+  int vals[3], got = 0;
+  while (got < 3) {
+    int c = in.peek();
+    if (c == '#') { std::string skip; std::getline(in, skip); continue; }
+    if (c == EOF) return false;
+    if (std::isspace(c)) { in.get(); continue; }
+    if (!(in >> vals[got])) return false;
+    ++got;
+  }
+  in.get();  // the single whitespace after maxval
+  if (vals[0] <= 0 || vals[1] <= 0 || vals[2] != 255) return false;
+  t.w = vals[0];
+  t.h = vals[1];
+  t.rgb.resize((size_t)t.w * t.h * 3);
+  in.read(reinterpret_cast<char *>(t.rgb.data()), (std::streamsize)t.rgb.size());
+  return (size_t)in.gcount() == t.rgb.size();
+}
+
 static void load_mtl(const std::string &path, World &w, std::map<std::string, int> &names) {
+  static const std::regex r_map("^\\s*map_Kd\\s+(.*?)\\s*$");
   static const std::regex r_new("^\\s*newmtl\\s+(.*?)\\s*$");
   static const std::regex r_kd("^\\s*Kd\\s+([0-9.]+)\\s+([0-9.]+)\\s+([0-9.]+)\\s*$");
   static const std::regex r_ke("^\\s*Ke\\s+([0-9.]+)\\s+([0-9.]+)\\s+([0-9.]+)\\s*$");
@@ -366,6 +415,16 @@ static void load_mtl(const std::string &path, World &w, std::map<std::string, in
       if (cur >= 0) w.mats[cur].kd = V3(std::stof(m[1].str()), std::stof(m[2].str()), std::stof(m[3].str()));
     } else if (std::regex_match(line, m, r_ke)) {
       if (cur >= 0) w.mats[cur].ke = V3(std::stof(m[1].str()), std::stof(m[2].str()), std::stof(m[3].str()));
+    } else if (std::regex_match(line, m, r_map)) {  // object.cpp:576-579: relative to the .mtl file
+      if (cur >= 0) {
+        Tex t;
+        if (!load_ppm(dir_of(path) + m[1].str(), t)) {
+          w.error = "cannot read texture " + m[1].str() + " (binary PPM expected)";
+          return;
+        }
+        w.textures.push_back(std::move(t));
+        w.mats[cur].tex = (int)w.textures.size() - 1;
+      }
     }
   }
 }
@@ -398,18 +457,26 @@ static World *load_obj(const std::string &path) {
   struct Pending {
     Mesh m;
     std::vector<std::vector<uint32_t>> faces;
-    size_t nvt = 0, nvn = 0;
+    std::vector<std::vector<uint32_t>> faces_vt;  // the vt index of every corner (0xffffffff: the a//c form has none)
+    size_t nvn = 0;
   };
   Pending *cur = nullptr;
-  float off_v = 0;  // veci stores floats, math.cpp:22,191
+  float off_v = 0, off_vt = 0;  // veci stores floats, math.cpp:22,191
   bool ok = true;
   auto close = [&]() {
     if (!cur) return;
-    for (auto &f : cur->faces)  // fan about corner 0, object.cpp:478-490
-      for (size_t i = 1; i + 1 < f.size(); ++i) cur->m.tris.push_back(Tri{f[0], f[i], f[i + 1]});
+    for (size_t k = 0; k < cur->faces.size(); ++k) {  // fan about corner 0, object.cpp:478-490
+      const auto &f = cur->faces[k];
+      const auto &ft = cur->faces_vt[k];
+      for (size_t i = 1; i + 1 < f.size(); ++i) {
+        cur->m.tris.push_back(Tri{f[0], f[i], f[i + 1]});
+        cur->m.tri_vt.push_back(Tri{ft[0], ft[i], ft[i + 1]});
+      }
+    }
     if (cur->m.mat < 0) cur->m.mat = 0;
     if (!finish_mesh(*w, cur->m)) ok = false;
     off_v += (float)cur->m.verts.size();
+    off_vt += (float)cur->m.vts.size();  // object.cpp:679-680
     w->meshes.push_back(std::move(cur->m));
     delete cur;
     cur = nullptr;
@@ -425,24 +492,35 @@ static World *load_obj(const std::string &path) {
       ++cur->nvn;
     } else if (std::regex_match(line, m, r_vt)) {
       if (!cur) { w->error = "vt before o"; ok = false; break; }
-      ++cur->nvt;
+      cur->m.vts.push_back(V3(std::stof(m[1].str()), m[2].matched ? std::stof(m[2].str()) : 0,
+                              m[3].matched ? std::stof(m[3].str()) : 0));  // object.cpp:662-668
     } else if (std::regex_match(line, m, r_f3) || std::regex_match(line, m, r_f2)) {
       if (!cur) { w->error = "f before o"; ok = false; break; }
       bool three = std::regex_match(line, r_f3);
       const std::regex &cr = three ? c_f3 : c_f2;
-      std::vector<uint32_t> face;
+      std::vector<uint32_t> face, face_vt;
       for (std::sregex_iterator it(line.begin(), line.end(), cr), e; it != e; ++it) {
         float idx = (float)std::stoi((*it)[1].str());  // object.cpp:620,629-635
         idx -= 1;
         idx -= off_v;
         face.push_back((uint32_t)idx);
+        if (three) {
+          float ti = (float)std::stoi((*it)[2].str());
+          ti -= 1;
+          ti -= off_vt;
+          face_vt.push_back(ti >= 0 ? (uint32_t)ti : 0xffffffffu);
+        } else {
+          face_vt.push_back(0xffffffffu);  // veci(l[0], 0, l[1]) - 1 is negative there, object.cpp:672
+        }
       }
       cur->faces.push_back(face);
+      cur->faces_vt.push_back(face_vt);
     } else if (std::regex_match(line, m, r_o)) {
       close();
       cur = new Pending();
     } else if (std::regex_match(line, m, r_lib)) {
       load_mtl(dir_of(path) + m[1].str(), *w, names);
+      if (!w->error.empty()) { ok = false; break; }
     } else if (std::regex_match(line, m, r_use)) {
       if (!cur) { w->error = "usemtl before o"; ok = false; break; }
       auto f = names.find(m[1].str());
@@ -610,7 +688,27 @@ static V3 direct_light(const Frame &f, V3 x, V3 n, Rng &rng, uint32_t base) {
 struct Vertex {
   V3 x, n;
   const Mat *mat;
+  bool textured;
+  V3 texel;  // the brdf of a textured vertex, camera.cpp:124-146
 };
+
+// static_cast<int>(scalar) of camera.cpp:142-143 as x86-64 performs it (cvttss2si): INT_MIN when
+// the value does not fit.
+static inline int cvt_int(float f) {
+  return (f >= 2147483648.0f || f < -2147483648.0f || f != f) ? (int)0x80000000 : (int)f;
+}
+static inline V3 texel_brdf(const World &w, const Mesh &m, const Hit &h) {
+  const float beta = h.u, gamma = h.v, alpha = h.w;  // auto [beta,gamma,alpha] = hit.barycentric, camera.cpp:124
+  const Tri &vt = m.tri_vt[h.tri];
+  const V3 t0 = m.vts[vt.a], t1 = m.vts[vt.b], t2 = m.vts[vt.c];
+  const float u = alpha * t0.x + beta * t1.x + gamma * t2.x;  // camera.cpp:137-138
+  const float v = alpha * t0.y + beta * t1.y + gamma * t2.y;
+  const Tex &img = w.textures[w.mats[m.mat].tex];
+  const int x = std::clamp(cvt_int(u * img.w), 0, img.w - 1);  // camera.cpp:141-145
+  const int y = std::clamp(cvt_int(v * img.h), 0, img.h - 1);
+  const uint8_t *p = &img.rgb[((size_t)y * img.w + x) * 3];
+  return divs(V3(p[0], p[1], p[2]), 255);  // Image::at, object.cpp:128-134
+}
 static inline Vertex shade_setup(const World &w, const Hit &h, V3 o, V3 d) {
   Vertex v;
   v.x = add(o, scale(d, h.t));  // camera.cpp:68
@@ -618,6 +716,8 @@ static inline Vertex shade_setup(const World &w, const Hit &h, V3 o, V3 d) {
   v.n = normalize(tri_normal(m, m.tris[h.tri]));  // camera.cpp:69
   if (dot(v.n, normalize(d)) > 0) v.n = neg(v.n);  // camera.cpp:72-73
   v.mat = &w.mats[m.mat];
+  v.textured = v.mat->tex >= 0;
+  if (v.textured) v.texel = texel_brdf(w, m, h);
   return v;
 }
 static inline bool keep_going(const Frame &f, int depth, Rng &rng, uint32_t base) {
@@ -648,9 +748,9 @@ static V3 trace_recursive(const Frame &f, V3 o, V3 d, int depth, Rng &rng) {
     color = add(color, v.mat->ke);
     V3 child = trace_recursive(f, v.x, w, depth + 1, rng);
     if (f.opt.sampling == PT_SAMPLE_COSINE) {
-      color = add(color, divs(mul(child, v.mat->kd), f.opt.rr_prob));
+      color = add(color, divs(mul(child, v.textured ? scale(v.texel, (float)M_PI) : v.mat->kd), f.opt.rr_prob));
     } else {
-      V3 brdf = divs(v.mat->kd, (float)M_PI);
+      V3 brdf = v.textured ? v.texel : divs(v.mat->kd, (float)M_PI);  // camera.cpp:121-146
       color = add(color, divs(scale(mul(child, brdf), std::abs(dot(v.n, w))), pdf_f(f)));
     }
   }
@@ -677,9 +777,9 @@ static V3 trace_iterative(const Frame &f, V3 o, V3 d, Rng &rng) {
     if (!cont) break;
     V3 w = next_dir(f, v.n, rng, base);
     if (f.opt.sampling == PT_SAMPLE_COSINE) {
-      T = divs(mul(T, v.mat->kd), f.opt.rr_prob);
+      T = divs(mul(T, v.textured ? scale(v.texel, (float)M_PI) : v.mat->kd), f.opt.rr_prob);
     } else {
-      V3 brdf = divs(v.mat->kd, (float)M_PI);
+      V3 brdf = v.textured ? v.texel : divs(v.mat->kd, (float)M_PI);
       T = divs(scale(mul(T, brdf), std::abs(dot(v.n, w))), pdf_f(f));
     }
     o = v.x;
@@ -760,6 +860,42 @@ void orc_counts(const World *w, uint32_t *n_meshes, uint32_t *n_tris, uint32_t *
 }
 
 // Everything a PtSceneDesc needs, copied into caller-allocated arrays.
+// Textures and texture coordinates, in the shape PtSceneDesc wants them.
+uint32_t orc_n_textures(const World *w) { return (uint32_t)w->textures.size(); }
+void orc_texture_size(const World *w, uint32_t i, uint32_t *width, uint32_t *height) {
+  *width = (uint32_t)w->textures[i].w;
+  *height = (uint32_t)w->textures[i].h;
+}
+void orc_texture_data(const World *w, uint32_t i, uint8_t *rgb) {
+  std::memcpy(rgb, w->textures[i].rgb.data(), w->textures[i].rgb.size());
+}
+// The brdf camera.cpp:124-146 takes from the diffuse map for a hit on triangle `tri` of `mesh`
+// with barycentrics (u, v); returns 0 when the mesh's material has no map.
+int orc_texel(const World *w, uint32_t mesh, uint32_t tri, float u, float v, float *rgb) {
+  const Mesh &m = w->meshes[mesh];
+  if (w->mats[m.mat].tex < 0) return 0;
+  Hit h;
+  h.mesh = (int)mesh; h.tri = (int)tri; h.u = u; h.v = v; h.w = 1 - u - v;
+  const V3 c = texel_brdf(*w, m, h);
+  rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+  return 1;
+}
+
+void orc_export_textured(const World *w, int32_t *material_texture, float *tri_uv) {
+  for (size_t i = 0; i < w->mats.size(); ++i) material_texture[i] = w->mats[i].tex;
+  size_t t = 0;
+  for (const Mesh &m : w->meshes)
+    for (size_t k = 0; k < m.tris.size(); ++k, ++t) {
+      const bool has = m.tri_vt.size() == m.tris.size() && m.tri_vt[k].a < m.vts.size() && m.tri_vt[k].b < m.vts.size() &&
+                       m.tri_vt[k].c < m.vts.size();
+      const uint32_t id[3] = {has ? m.tri_vt[k].a : 0, has ? m.tri_vt[k].b : 0, has ? m.tri_vt[k].c : 0};
+      for (int c = 0; c < 3; ++c) {
+        tri_uv[t * 6 + c * 2 + 0] = has ? m.vts[id[c]].x : 0.0f;
+        tri_uv[t * 6 + c * 2 + 1] = has ? m.vts[id[c]].y : 0.0f;
+      }
+    }
+}
+
 void orc_export(const World *w, PtNode *tlas_nodes, uint32_t *tlas_order, uint32_t *blas_node_offset,
                 PtNode *blas_nodes, uint32_t *tri_offset, uint32_t *blas_order, float *tri_verts,
                 uint32_t *mesh_material, PtMaterial *mats, uint32_t *lights, double *mesh_area) {

@@ -91,6 +91,13 @@ def lib():
         L.orc_from_arrays.restype = C.c_void_p
         L.orc_from_arrays.argtypes = [C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 6
+        L.orc_n_textures.restype = C.c_uint32
+        L.orc_n_textures.argtypes = [C.c_void_p]
+        L.orc_texture_size.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_texture_data.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_export_textured.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_texel.restype = C.c_int
+        L.orc_texel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         L.orc_export.argtypes = [C.c_void_p] * 12
         L.orc_castray.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 12
         L.orc_camera_rays.argtypes = [C.POINTER(PtCamera), C.c_int32, C.c_int32, C.c_void_p]
@@ -168,7 +175,25 @@ class World:
         lib().orc_export(self._h, *[_p(d[k]) for k in (
             "tlas_nodes", "tlas_order", "blas_node_offset", "blas_nodes", "tri_offset", "blas_order",
             "tri_verts", "mesh_material", "materials", "lights", "mesh_area")])
+        nt = lib().orc_n_textures(self._h)
+        if nt:
+            texs = []
+            for i in range(nt):
+                w, h = C.c_uint32(), C.c_uint32()
+                lib().orc_texture_size(self._h, i, C.byref(w), C.byref(h))
+                t = np.zeros((h.value, w.value, 3), np.uint8)
+                lib().orc_texture_data(self._h, i, _p(t))
+                texs.append(t)
+            d["textures"] = texs
+            d["material_texture"] = np.zeros(self.n_mats, np.int32)
+            d["tri_uv"] = np.zeros((self.n_tris, 3, 2), np.float32)
+            lib().orc_export_textured(self._h, _p(d["material_texture"]), _p(d["tri_uv"]))
         return d
+
+    def texel(self, mesh, tri, u, v):
+        """brdf taken from the diffuse map (camera.cpp:124-146), or None for an untextured mesh."""
+        rgb = np.zeros(3, np.float32)
+        return rgb if lib().orc_texel(self._h, mesh, tri, u, v, _p(rgb)) else None
 
     def castray(self, o, d, want_hits=False, want_counters=False):
         """o, d: [n,3] float32.  Returns dict(t, tri, u, v[, hits][, nodes, tris])."""

@@ -24,12 +24,18 @@ class PtMaterial(C.Structure):
     _fields_ = [("kd", C.c_float * 3), ("ke", C.c_float * 3)]
 
 
+class PtTexture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.c_void_p)]
+
+
 class PtSceneDesc(C.Structure):
     _fields_ = [("n_meshes", C.c_uint32), ("n_tris", C.c_uint32), ("n_materials", C.c_uint32),
                 ("n_tlas_nodes", C.c_uint32),
                 ("tlas_nodes", C.c_void_p), ("tlas_order", C.c_void_p), ("blas_node_offset", C.c_void_p),
                 ("blas_nodes", C.c_void_p), ("tri_offset", C.c_void_p), ("blas_order", C.c_void_p),
-                ("tri_verts", C.c_void_p), ("mesh_material", C.c_void_p), ("materials", C.c_void_p)]
+                ("tri_verts", C.c_void_p), ("mesh_material", C.c_void_p), ("materials", C.c_void_p),
+                ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("material_texture", C.c_void_p),
+                ("tri_uv", C.c_void_p)]
 
 
 class PtSceneInfo(C.Structure):
@@ -177,7 +183,8 @@ def resolve(accum, spp):
 class DeviceScene:
     """A scene resident in HBM.  `arrays` is a dict with the members of PtSceneDesc as numpy
     arrays (tlas_nodes, tlas_order, blas_node_offset, blas_nodes, tri_offset, blas_order, tri_verts,
-    mesh_material, materials)."""
+    mesh_material, materials), and optionally textures (list of [H,W,3] uint8 arrays), material_texture
+    (int32 per material, -1 = none) and tri_uv ([n_tris,3,2] float32)."""
 
     def __init__(self, arrays, device=0):
         self._h = None
@@ -208,6 +215,23 @@ class DeviceScene:
         d.n_tlas_nodes = len(a["tlas_nodes"])
         for k, v in a.items():
             setattr(d, k, v.ctypes.data)
+        texs = [np.ascontiguousarray(t, np.uint8) for t in arrays.get("textures", [])]
+        if texs:
+            for t in texs:
+                if t.ndim != 3 or t.shape[2] != 3 or t.size == 0:
+                    raise ValueError("a texture must be a non-empty [H,W,3] uint8 array")
+            mt = np.ascontiguousarray(arrays["material_texture"], np.int32)
+            if len(mt) != d.n_materials:
+                raise ValueError("material_texture must have one entry per material")
+            recs = (PtTexture * len(texs))()
+            for r, t in zip(recs, texs):
+                r.width, r.height, r.rgb = t.shape[1], t.shape[0], t.ctypes.data
+            d.n_textures, d.textures, d.material_texture = len(texs), C.addressof(recs), mt.ctypes.data
+            if arrays.get("tri_uv") is not None:
+                uv = np.ascontiguousarray(arrays["tri_uv"], np.float32)
+                if uv.size != nt * 6:
+                    raise ValueError("tri_uv must be [n_tris,3,2]")
+                d.tri_uv = uv.ctypes.data
         h = C.c_void_p()
         _check(lib().pt_scene_upload(C.byref(d), device, C.byref(h)))
         self._h = h

@@ -51,6 +51,26 @@ void *pth_scene_from_cache(const char *path) {
   return h;
 }
 
+// Decodes an image file as a diffuse map is decoded; rgb may be null to query the size only.
+int pth_load_image(const char *path, uint32_t *width, uint32_t *height, uint8_t *rgb, size_t cap) {
+  Image img;
+  std::string err;
+  if (!load_image(path, img, err)) {
+    g_err = err;
+    return -1;
+  }
+  *width = img.width;
+  *height = img.height;
+  if (rgb) {
+    if (cap < img.rgb.size()) {
+      g_err = "buffer too small";
+      return -1;
+    }
+    memcpy(rgb, img.rgb.data(), img.rgb.size());
+  }
+  return 0;
+}
+
 int pth_scene_save_cache(void *h, const char *path) {
   std::string err;
   if (!static_cast<Handle *>(h)->scene.save_cache(path, &err)) {

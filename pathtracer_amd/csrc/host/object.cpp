@@ -204,8 +204,8 @@ bool to_float(const std::string &s, size_t b, size_t e, float &out) {
   return end != p && errno != ERANGE;
 }
 
-// one face corner "a/b/c" or "a//c"; returns the first integer
-bool corner_index(const std::string &s, size_t b, size_t e, bool &three, long &idx) {
+// one face corner "a/b/c" or "a//c"; returns the first integer and, for a/b/c, the second
+bool corner_index(const std::string &s, size_t b, size_t e, bool &three, long &idx, long &vt) {
   size_t i = b;
   auto digits = [&](long *val) {
     size_t st = i;
@@ -229,7 +229,7 @@ bool corner_index(const std::string &s, size_t b, size_t e, bool &three, long &i
     return i == e;
   }
   three = true;
-  if (!digits(nullptr)) return false;
+  if (!digits(&vt)) return false;
   if (i >= e || s[i] != '/') return false;
   ++i;
   if (!digits(nullptr)) return false;
@@ -256,7 +256,8 @@ bool rest_after_keyword(const std::string &line, const std::vector<std::pair<siz
   return true;
 }
 
-void parsemtl(const std::string &filename, std::vector<Material> &mats, std::map<std::string, int> &names) {
+bool parsemtl(const std::string &filename, std::vector<Material> &mats, std::vector<Image> &textures,
+              std::map<std::string, int> &names, std::string &err) {
   std::ifstream in(filename);  // a missing file is silently empty (object.cpp:581)
   std::string line;
   std::vector<std::pair<size_t, size_t>> tk;
@@ -281,9 +282,16 @@ void parsemtl(const std::string &filename, std::vector<Material> &mats, std::map
       (key == "Kd" ? mats[cur].diffuse : mats[cur].emission) = vec(f[0], f[1], f[2]);
     } else if (key == "map_Kd") {
       std::string name;
-      if (cur >= 0 && rest_after_keyword(line, tk, name)) mats[cur].diffuse_map = directory_of(filename) + name;
+      if (cur >= 0 && rest_after_keyword(line, tk, name)) {  // object.cpp:576-579
+        mats[cur].diffuse_map = directory_of(filename) + name;
+        Image img;
+        if (!load_image(mats[cur].diffuse_map, img, err)) return false;  // the reference aborts, object.cpp:40-52
+        textures.push_back(std::move(img));
+        mats[cur].texture = (int)textures.size() - 1;
+      }
     }
   }
+  return true;
 }
 
 }  // namespace
@@ -300,11 +308,19 @@ bool parseobj(const std::string &filename, ParsedScene &out, std::string &err) {
   std::map<std::string, int> names;
   Polygon *cur = nullptr;
   Polygon pending;
-  float offset_v = 0;  // the reference keeps index offsets in a float vector (math.cpp:22, object.cpp:599)
+  float offset_v = 0, offset_vt = 0;  // the reference keeps index offsets in a float vector (math.cpp:22, object.cpp:599)
   auto close_current = [&]() -> bool {
     if (!cur) return true;
     if (!cur->init(&err)) return false;
+    if (out.materials[cur->material].texture >= 0)  // Triangle::vt0/vt1/vt2 assert this, object.cpp:542-553
+      for (const auto &t : cur->tri_vt)
+        for (uint32_t id : t)
+          if (id >= cur->vtextures.size()) {
+            err = filename + ": textured object with a face whose texture coordinate is missing or outside its own object";
+            return false;
+          }
     offset_v += (float)cur->vertices.size();
+    offset_vt += (float)cur->vtextures.size();
     out.meshes.push_back(std::move(*cur));
     pending = Polygon();
     cur = nullptr;
@@ -343,27 +359,33 @@ bool parseobj(const std::string &filename, ParsedScene &out, std::string &err) {
       for (size_t c = 1; c < tk.size(); ++c) syn = syn && number_syntax(line, tk[c].first, tk[c].second, true);
       if (syn) {
         if (!cur) return at("vertex data before the first 'o' line");
-        for (size_t c = 1; c < tk.size(); ++c) {
-          float f;
-          if (!to_float(line, tk[c].first, tk[c].second, f)) return at("number that std::stof rejects");
-        }
-        continue;  // texture coordinates are parsed for validity only
+        float f[3] = {0, 0, 0};  // missing components are 0, object.cpp:662-668
+        for (size_t c = 1; c < tk.size(); ++c)
+          if (!to_float(line, tk[c].first, tk[c].second, f[c - 1])) return at("number that std::stof rejects");
+        cur->vtextures.push_back(vec(f[0], f[1], f[2]));
+        continue;
       }
     }
     if (kl == 1 && k[0] == 'f' && tk.size() >= 2) {
       bool syn = true, three0 = false;
-      std::vector<long> idx(tk.size() - 1);
+      std::vector<long> idx(tk.size() - 1), vti(tk.size() - 1, -1);
       for (size_t c = 1; c < tk.size() && syn; ++c) {
         bool three = false;
-        syn = corner_index(line, tk[c].first, tk[c].second, three, idx[c - 1]);
+        syn = corner_index(line, tk[c].first, tk[c].second, three, idx[c - 1], vti[c - 1]);
         if (c == 1) three0 = three;
         else if (three != three0) syn = false;  // one line matches one of the two face patterns
       }
       if (syn) {
         if (!cur) return at("face before the first 'o' line");
         if (idx.size() < 3) return at("face with fewer than three corners");
-        std::vector<uint32_t> corner(idx.size());
+        std::vector<uint32_t> corner(idx.size()), corner_vt(idx.size(), 0xffffffffu);
         for (size_t c = 0; c < idx.size(); ++c) {
+          if (three0 && vti[c] >= 0) {  // the a//c form has no texture coordinate (veci(l[0], 0, l[1]), object.cpp:672)
+            float t = (float)(int)vti[c];
+            t -= 1;
+            t -= offset_vt;
+            if (t >= 0) corner_vt[c] = (uint32_t)t;
+          }
           if (idx[c] < 0) return at("face index that std::stoi rejects");
           float v = (float)(int)idx[c];  // object.cpp:620,629-635
           v -= 1;
@@ -372,7 +394,10 @@ bool parseobj(const std::string &filename, ParsedScene &out, std::string &err) {
           corner[c] = (uint32_t)v;
         }
         for (size_t c = 1; c + 1 < corner.size(); ++c)  // fan about corner 0, object.cpp:478-490
+        {
           cur->triangles.push_back({corner[0], corner[c], corner[c + 1]});
+          cur->tri_vt.push_back({corner_vt[0], corner_vt[c], corner_vt[c + 1]});
+        }
         continue;
       }
     }
@@ -389,7 +414,7 @@ bool parseobj(const std::string &filename, ParsedScene &out, std::string &err) {
     if (kl == 6 && memcmp(k, "mtllib", 6) == 0) {
       std::string name;
       if (rest_after_keyword(line, tk, name)) {
-        parsemtl(directory_of(filename) + name, out.materials, names);
+        if (!parsemtl(directory_of(filename) + name, out.materials, out.textures, names, err)) return false;
         continue;
       }
     }

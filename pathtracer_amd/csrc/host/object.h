@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../../include/ptgpu.h"
+#include "image.h"
 #include "math.h"
 
 namespace pt {
@@ -18,7 +19,8 @@ namespace pt {
 struct Material {  // object.cpp:144-156; only the fields the integrator reads
   vec diffuse = vec(.5f, .5f, .5f);
   vec emission = vec(0, 0, 0);
-  std::string diffuse_map;  // path named by map_Kd; textures are not decoded (no FFmpeg)
+  std::string diffuse_map;  // path named by map_Kd
+  int texture = -1;         // index into ParsedScene::textures / Scene::textures; -1 = diffuse_map == nullptr
 };
 
 struct AABB {  // object.cpp:160-196
@@ -49,6 +51,8 @@ class Polygon {
  public:
   std::vector<vec> vertices;
   std::vector<std::array<uint32_t, 3>> triangles;  // vertex ids local to this mesh, creation order
+  std::vector<vec> vtextures;                       // object.cpp:453
+  std::vector<std::array<uint32_t, 3>> tri_vt;      // Triangle::vt per triangle; 0xffffffff where a corner has none
   int material = 0;                                 // index into the owning material table
   double area_ = 0;                                 // sum of XY-projected triangle areas, object.cpp:493-495
   BVH bvh;
@@ -69,6 +73,7 @@ class Polygon {
 struct ParsedScene {
   std::vector<Polygon> meshes;
   std::vector<Material> materials;  // [0] is the default material of Object::Object (object.cpp:209)
+  std::vector<Image> textures;      // decoded diffuse maps
 };
 
 // parseobj (object.cpp:595-710) for the dialect its regular expressions accept.

@@ -8,7 +8,8 @@
 
 namespace pt {
 
-Scene::Scene(ParsedScene &&parsed) : meshes(std::move(parsed.meshes)), materials(std::move(parsed.materials)) {
+Scene::Scene(ParsedScene &&parsed)
+    : meshes(std::move(parsed.meshes)), materials(std::move(parsed.materials)), textures(std::move(parsed.textures)) {
   std::vector<AABB> boxes(meshes.size());
   for (size_t i = 0; i < meshes.size(); ++i) boxes[i] = meshes[i].bbox();
   objects = BVH(boxes);
@@ -21,6 +22,7 @@ Scene &Scene::operator=(Scene &&o) noexcept {
     if (dev_) pt_scene_free(dev_);
     meshes = std::move(o.meshes);
     materials = std::move(o.materials);
+    textures = std::move(o.textures);
     objects = std::move(o.objects);
     desc_ready_ = false;  // pointers in desc_ refer to the vectors below; rebuild lazily
     cached_ = o.cached_;
@@ -32,6 +34,8 @@ Scene &Scene::operator=(Scene &&o) noexcept {
       blas_nodes_ = std::move(o.blas_nodes_);
       tri_verts_ = std::move(o.tri_verts_);
       mats_ = std::move(o.mats_);
+      tri_uv_ = std::move(o.tri_uv_);
+      material_texture_ = std::move(o.material_texture_);
       point_desc();
     }
     dev_ = o.dev_;
@@ -87,6 +91,16 @@ void Scene::point_desc() const {
   desc_.tri_verts = tri_verts_.data();
   desc_.mesh_material = mesh_material_.data();
   desc_.materials = mats_.data();
+  tex_desc_.resize(textures.size());
+  for (size_t i = 0; i < textures.size(); ++i) {
+    tex_desc_[i].width = textures[i].width;
+    tex_desc_[i].height = textures[i].height;
+    tex_desc_[i].rgb = textures[i].rgb.data();
+  }
+  desc_.n_textures = (uint32_t)textures.size();
+  desc_.textures = textures.empty() ? nullptr : tex_desc_.data();
+  desc_.material_texture = textures.empty() ? nullptr : material_texture_.data();
+  desc_.tri_uv = textures.empty() ? nullptr : tri_uv_.data();
   desc_ready_ = true;
 }
 
@@ -125,6 +139,21 @@ void Scene::build_desc() const {
   for (size_t i = 0; i < materials.size(); ++i) {
     mats_[i].kd[0] = materials[i].diffuse.x; mats_[i].kd[1] = materials[i].diffuse.y; mats_[i].kd[2] = materials[i].diffuse.z;
     mats_[i].ke[0] = materials[i].emission.x; mats_[i].ke[1] = materials[i].emission.y; mats_[i].ke[2] = materials[i].emission.z;
+  }
+  tri_uv_.clear();
+  material_texture_.clear();
+  if (!textures.empty()) {
+    material_texture_.resize(materials.size());
+    for (size_t i = 0; i < materials.size(); ++i) material_texture_[i] = materials[i].texture;
+    tri_uv_.reserve((size_t)tri_offset_[nm] * 6);
+    for (const Polygon &m : meshes)
+      for (size_t t = 0; t < m.triangles.size(); ++t)
+        for (int c = 0; c < 3; ++c) {
+          const uint32_t id = m.tri_vt.size() == m.triangles.size() ? m.tri_vt[t][c] : 0xffffffffu;
+          const bool has = id < m.vtextures.size();  // untextured objects may lack coordinates
+          tri_uv_.push_back(has ? m.vtextures[id].x : 0.0f);
+          tri_uv_.push_back(has ? m.vtextures[id].y : 0.0f);
+        }
   }
   point_desc();
 }
@@ -185,12 +214,14 @@ HitData Scene::castray(vec origin, vec direction) const {
 }
 
 // ---------------------------------------------------------------- cache file
-// Layout (little endian): magic "PTSCENE1", seven uint32 counts (meshes, triangles, materials,
+// Layout (little endian): magic "PTSCENE2", seven uint32 counts (meshes, triangles, materials,
 // top-level nodes, mesh nodes, sizeof(PtNode), sizeof(PtMaterial)), a 64-bit FNV-1a hash of the
-// payload, then the payload: the arrays of PtSceneDesc in declaration order.
+// payload, then the payload: the arrays of PtSceneDesc in declaration order; after them a
+// uint32 texture count and, when it is not 0, width and height of every texture, the
+// material_texture and tri_uv arrays and the texels.
 namespace {
 
-const char kMagic[8] = {'P', 'T', 'S', 'C', 'E', 'N', 'E', '1'};
+const char kMagic[8] = {'P', 'T', 'S', 'C', 'E', 'N', 'E', '2'};
 
 struct Fnv {
   uint64_t h = 1469598103934665603ull;
@@ -224,12 +255,26 @@ bool Scene::save_cache(const std::string &path, std::string *err) const {
       {d.mesh_material, (size_t)d.n_meshes * 4},
       {d.materials, (size_t)d.n_materials * sizeof(PtMaterial)},
   };
+  std::vector<Part> all(parts, parts + 9);
+  const uint32_t n_tex = d.n_textures;
+  std::vector<uint32_t> dims;
+  all.push_back({&n_tex, 4});
+  if (n_tex) {
+    for (uint32_t t = 0; t < n_tex; ++t) {
+      dims.push_back(d.textures[t].width);
+      dims.push_back(d.textures[t].height);
+    }
+    all.push_back({dims.data(), dims.size() * 4});
+    all.push_back({d.material_texture, (size_t)d.n_materials * 4});
+    all.push_back({d.tri_uv, (size_t)d.n_tris * 24});
+    for (uint32_t t = 0; t < n_tex; ++t) all.push_back({d.textures[t].rgb, (size_t)d.textures[t].width * d.textures[t].height * 3});
+  }
   Fnv f;
-  for (const Part &q : parts) f.add(q.p, q.n);
+  for (const Part &q : all) f.add(q.p, q.n);
   FILE *fp = std::fopen(path.c_str(), "wb");
   if (!fp) return set_err(err, "cannot open " + path + " for writing");
   bool ok = std::fwrite(kMagic, 1, 8, fp) == 8 && std::fwrite(head, 4, 7, fp) == 7 && std::fwrite(&f.h, 8, 1, fp) == 1;
-  for (const Part &q : parts) ok = ok && (q.n == 0 || std::fwrite(q.p, 1, q.n, fp) == q.n);
+  for (const Part &q : all) ok = ok && (q.n == 0 || std::fwrite(q.p, 1, q.n, fp) == q.n);
   ok = (std::fclose(fp) == 0) && ok;
   if (!ok) return set_err(err, "short write to " + path);
   return true;
@@ -254,7 +299,7 @@ bool Scene::load_cache(const std::string &path, Scene &out, std::string *err) {
   std::fseek(fp, 0, SEEK_END);
   const long size = std::ftell(fp);
   std::fseek(fp, 8 + 28 + 8, SEEK_SET);
-  if (size < 0 || (uint64_t)size != 8 + 28 + 8 + payload || nm == 0) {
+  if (size < 0 || (uint64_t)size < 8 + 28 + 8 + payload + 4 || nm == 0) {
     std::fclose(fp);
     return set_err(err, path + ": size does not match its header");
   }
@@ -282,8 +327,48 @@ bool Scene::load_cache(const std::string &path, Scene &out, std::string *err) {
     ok = ok && (q.n == 0 || std::fread(q.p, 1, q.n, fp) == q.n);
     if (ok) f.add(q.p, q.n);
   }
+  // texture section: every count is checked against what is left of the file before it is used
+  uint64_t left = (uint64_t)size - (8 + 28 + 8 + payload);
+  uint32_t n_tex = 0;
+  ok = ok && std::fread(&n_tex, 4, 1, fp) == 1;
+  if (ok) f.add(&n_tex, 4);
+  left -= 4;
+  if (ok && n_tex) {
+    std::vector<uint32_t> dims((size_t)2 * (n_tex <= left / 8 ? n_tex : 0));
+    ok = !dims.empty() && std::fread(dims.data(), 4, dims.size(), fp) == dims.size();
+    uint64_t need = (uint64_t)nmat * 4 + (uint64_t)nt * 24;
+    if (ok) {
+      f.add(dims.data(), dims.size() * 4);
+      left -= dims.size() * 4;
+      for (uint32_t t = 0; t < n_tex && ok; ++t) {
+        ok = dims[2 * t] != 0 && dims[2 * t + 1] != 0 && (uint64_t)dims[2 * t] * dims[2 * t + 1] <= (1ull << 28);
+        need += (uint64_t)dims[2 * t] * dims[2 * t + 1] * 3;
+      }
+    }
+    ok = ok && need == left;
+    if (ok) {
+      s.material_texture_.resize(nmat);
+      s.tri_uv_.resize((size_t)nt * 6);
+      ok = std::fread(s.material_texture_.data(), 4, nmat, fp) == nmat && std::fread(s.tri_uv_.data(), 4, (size_t)nt * 6, fp) == (size_t)nt * 6;
+      if (ok) {
+        f.add(s.material_texture_.data(), (size_t)nmat * 4);
+        f.add(s.tri_uv_.data(), (size_t)nt * 24);
+      }
+      s.textures.resize(n_tex);
+      for (uint32_t t = 0; t < n_tex && ok; ++t) {
+        Image &img = s.textures[t];
+        img.width = dims[2 * t];
+        img.height = dims[2 * t + 1];
+        img.rgb.resize((size_t)img.width * img.height * 3);
+        ok = std::fread(img.rgb.data(), 1, img.rgb.size(), fp) == img.rgb.size();
+        if (ok) f.add(img.rgb.data(), img.rgb.size());
+      }
+    }
+  } else if (ok && left != 0) {
+    ok = false;
+  }
   std::fclose(fp);
-  if (!ok) return set_err(err, "short read from " + path);
+  if (!ok) return set_err(err, path + ": short or inconsistent file");
   if (f.h != want) return set_err(err, path + ": checksum mismatch");
   if (s.tri_offset_[nm] != nt || s.blas_node_offset_[nm] != nbl) return set_err(err, path + ": offsets do not end at the totals");
   for (uint32_t i = 0; i < nm; ++i)
@@ -292,6 +377,10 @@ bool Scene::load_cache(const std::string &path, Scene &out, std::string *err) {
   for (uint32_t i = 0; i < nmat; ++i) {
     s.materials[i].diffuse = vec(s.mats_[i].kd[0], s.mats_[i].kd[1], s.mats_[i].kd[2]);
     s.materials[i].emission = vec(s.mats_[i].ke[0], s.mats_[i].ke[1], s.mats_[i].ke[2]);
+    if (n_tex) {
+      if (s.material_texture_[i] < -1 || s.material_texture_[i] >= (int32_t)n_tex) return set_err(err, path + ": texture index out of range");
+      s.materials[i].texture = s.material_texture_[i];
+    }
   }
   out = std::move(s);  // the tree structure itself is validated by pt_scene_upload
   return true;

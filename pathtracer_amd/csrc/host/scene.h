@@ -14,6 +14,7 @@ class Scene {
  public:
   std::vector<Polygon> meshes;      // creation ("file") order
   std::vector<Material> materials;
+  std::vector<Image> textures;      // decoded diffuse maps; Material::texture indexes this
   BVH objects;                      // top-level tree over the meshes (scene.cpp:13); objects.objects
                                     // holds mesh ids in the order the build left them
 
@@ -62,6 +63,9 @@ class Scene {
   mutable std::vector<PtNode> blas_nodes_;
   mutable std::vector<float> tri_verts_;
   mutable std::vector<PtMaterial> mats_;
+  mutable std::vector<float> tri_uv_;            // only when a texture exists
+  mutable std::vector<int32_t> material_texture_;
+  mutable std::vector<PtTexture> tex_desc_;
   mutable PtScene *dev_ = nullptr;
   mutable int dev_ordinal_ = -1;
 };

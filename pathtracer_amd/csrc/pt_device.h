@@ -95,6 +95,10 @@ struct SceneDev {
   const ptl::MatRec *mats;
   const ptl::LightRec *lights;
   const ptl::LightTri *light_tris;
+  const float *tri_uv;            // 6 floats per triangle record, or null (no textured material)
+  const ptl::TexRec *textures;
+  const uint8_t *texels;
+  uint32_t n_tex;                 // 0 when no material has a diffuse map
   uint32_t n_nodes, n_tris, n_lights, n_mats;
   float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
   uint32_t quorum;      // lanes of a wave that must hold a parked leaf before triangles are tested (closest hit)

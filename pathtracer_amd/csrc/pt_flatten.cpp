@@ -423,7 +423,55 @@ struct Flattener {
         r.kd[k] = d.materials[i].kd[k];
         r.ke[k] = d.materials[i].ke[k];
       }
-      r.pad0 = r.pad1 = 0;
+      r.tex = 0;
+      r.pad1 = 0;
+    }
+    if (d.n_textures > 0) {
+      if (!d.textures || !d.material_texture) {
+        err = "n_textures > 0 but textures or material_texture is null";
+        return PT_ERR_INVALID;
+      }
+      bool used = false;
+      for (uint32_t i = 0; i < d.n_materials; ++i) {
+        const int32_t t = d.material_texture[i];
+        if (t < -1 || t >= (int32_t)d.n_textures) {
+          err = "material_texture out of range";
+          return PT_ERR_INVALID;
+        }
+        out.mats[i].tex = (uint32_t)(t + 1);
+        used = used || t >= 0;
+      }
+      if (used) {
+        if (!d.tri_uv) {
+          err = "a material has a diffuse map but tri_uv is null";
+          return PT_ERR_INVALID;
+        }
+        out.textures.resize(d.n_textures);
+        for (uint32_t t = 0; t < d.n_textures; ++t) {
+          const PtTexture &x = d.textures[t];
+          if (x.width == 0 || x.height == 0 || !x.rgb || (uint64_t)x.width * x.height > (1ull << 28)) {
+            err = "empty or oversized texture";
+            return PT_ERR_INVALID;
+          }
+          const size_t bytes = (size_t)x.width * x.height * 3;
+          if (out.texels.size() + bytes > 0xffffffffull) {
+            err = "more than 4 GB of texels";
+            return PT_ERR_UNSUPPORTED;
+          }
+          out.textures[t].offset = (uint32_t)out.texels.size();
+          out.textures[t].width = x.width;
+          out.textures[t].height = x.height;
+          out.textures[t].pad = 0;
+          out.texels.insert(out.texels.end(), x.rgb, x.rgb + bytes);
+        }
+        // texture coordinates follow their triangle records (leaf splitting reordered those)
+        out.tri_uv.assign(out.tris.size() * 6, 0.0f);
+        for (size_t s = 0; s < out.tris.size(); ++s) {
+          const uint32_t gid = out.tris[s].tri_id;
+          if (gid == 0xffffffffu) continue;
+          for (int k = 0; k < 6; ++k) out.tri_uv[s * 6 + k] = d.tri_uv[(size_t)gid * 6 + k];
+        }
+      }
     }
     build_lights();
     out.n_meshes = d.n_meshes;

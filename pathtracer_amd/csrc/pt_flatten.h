@@ -15,6 +15,9 @@ struct FlatScene {
   std::vector<TriRec> tris;          // in tie-rank order, plus one degenerate triangle at the end
   std::vector<uint8_t> tri_levels;   // per triangle record: internal nodes of the reference between the root and its leaf
   std::vector<MatRec> mats;
+  std::vector<TexRec> textures;      // empty when no material has a diffuse map
+  std::vector<uint8_t> texels;       // RGB bytes of all textures
+  std::vector<float> tri_uv;         // 6 floats per triangle record (u,v of vt0, vt1, vt2); empty without textures
   std::vector<LightRec> lights;
   std::vector<LightTri> light_tris;
   uint32_t max_depth = 0;            // stack entries the deepest descent needs

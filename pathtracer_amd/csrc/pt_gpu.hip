@@ -48,6 +48,8 @@ struct HitDev {  // closest hit of every queued ray
   float *t;
   float *nx, *ny, *nz;  // Triangle::normal() of the hit triangle, un-normalised
   uint32_t *mat;
+  float *u, *v;         // barycentrics and triangle record of the hit: written and read only when
+  uint32_t *slot;       // the scene has a textured material
 };
 
 struct FrameDev {
@@ -311,6 +313,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
         hit.t[i] = h.t;
         hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
         hit.mat[i] = h.mat;
+        if (S.n_tex) {
+          hit.u[i] = h.u; hit.v[i] = h.v;
+          hit.slot[i] = h.slot;
+        }
         alive_out[i] = survives(S, F, depth, q, (uint32_t)i, h.t) ? 1 : 0;
       });
   if (COUNT) {
@@ -478,6 +484,29 @@ __device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
   return add(add(scale(t1, lx), scale(t2, ly)), scale(n, lz));
 }
 
+// static_cast<int>(float) as the reference's x86-64 build performs it (cvttss2si): out of range
+// and NaN give INT_MIN.
+__device__ __forceinline__ int cvt_int_x86(float f) {
+  return (f >= 2147483648.0f || f < -2147483648.0f || f != f) ? (int)0x80000000 : (int)f;
+}
+
+// brdf of a vertex on a textured triangle, camera.cpp:124-146: texture coordinates interpolated
+// with alpha = 1-u-v on vt0, beta = u on vt1, gamma = v on vt2 (HitData::barycentric is
+// (u, v, 1-u-v), object.cpp:428), nearest texel, no flip, the texel itself (no 1/pi).
+__device__ __forceinline__ V3 texel_brdf(const SceneDev &S, uint32_t tex, uint32_t slot, float bu, float bv) {
+  const float *uv = S.tri_uv + (size_t)slot * 6;
+  const float beta = bu, gamma = bv, alpha = 1 - bu - bv;
+  const float tu = alpha * uv[0] + beta * uv[2] + gamma * uv[4];
+  const float tv = alpha * uv[1] + beta * uv[3] + gamma * uv[5];
+  const ptl::TexRec tr = S.textures[tex - 1u];
+  const int w = (int)tr.width, h = (int)tr.height;
+  int x = cvt_int_x86(tu * (float)w), y = cvt_int_x86(tv * (float)h);
+  x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);  // std::clamp
+  y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+  const uint8_t *px = S.texels + tr.offset + ((size_t)y * (size_t)w + (size_t)x) * 3;
+  return divs(mk((float)px[0], (float)px[1], (float)px[2]), 255.0f);  // Image::at, object.cpp:128-134
+}
+
 // One light of the direct-light loop (camera.cpp:96-115) for the vertex at x with shading normal
 // nrm: the direction `to` of the visibility ray and `w`, what the light adds to the vertex if that
 // ray hits anything (the reference adds it when the ray hits *something*, camera.cpp:101-102).
@@ -526,8 +555,8 @@ __device__ __forceinline__ void sample_light(const SceneDev &S, PathRng &rng, ui
 // PHASE 1 / 2 (scenes outside LDS): 1 prepares the visibility rays of every vertex and light
 // (ShadowDev), k_shadow_walk walks them with per-lane refill, 2 does the rest of the vertex
 // with the answers.  The weights w are added in light order in both forms, so the sums agree
-// bit for bit.
-template <int MODE, int BLOCK, bool COUNT, bool RES, int PHASE>
+// bit for bit.  TEX: the scene has a diffuse map (untextured scenes run without that code).
+template <int MODE, int BLOCK, bool COUNT, bool RES, int PHASE, bool TEX>
 __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth, uint32_t n,
                                                  QueueDev in, HitDev hit, QueueDev out, ShadowDev sd,
                                                  const unsigned long long *chunk_mask, const uint32_t *chunk_base,
@@ -612,12 +641,16 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
             const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
             const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
             V3 w;
+            const uint32_t tex = __float_as_uint(m0.w);
+            const bool textured = TEX && tex != 0;                                // camera.cpp:121
+            V3 texel = mk(0, 0, 0);
+            if (textured) texel = texel_brdf(S, tex, hit.slot[i], hit.u[i], hit.v[i]);
             if (F.sampling == PT_SAMPLE_COSINE) {
               w = cosine_dir(nrm, rx, ry);
-              T = divs(mul(T, kd), F.rr_prob);
+              T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob);
             } else {
               w = uniform_dir(nrm, rx, ry);
-              const V3 brdf = divs(kd, F.pi_f);                                   // camera.cpp:122
+              const V3 brdf = textured ? texel : divs(kd, F.pi_f);                // camera.cpp:122-146
               T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
             }
             o = x;  // no offset along the normal, camera.cpp:155
@@ -758,7 +791,7 @@ static int fail(int code, const std::string &msg) {
 
 struct Workspace {
   size_t cap = 0;
-  float *block = nullptr;  // 2 queues x 13 arrays + 5 hit arrays + 3 radiance arrays
+  float *block = nullptr;  // 2 queues x 13 arrays + 8 hit arrays + 3 radiance arrays
   QueueDev q[2];
   HitDev hit{};
   float *Lr = nullptr, *Lg = nullptr, *Lb = nullptr;
@@ -791,6 +824,9 @@ struct PtScene {
   ptl::LightRec *d_lights = nullptr;
   ptl::LightTri *d_ltris = nullptr;
   uint8_t *d_levels = nullptr;             // per triangle record: HitData::hits of a hit on it
+  float *d_tri_uv = nullptr;               // textured scenes only
+  ptl::TexRec *d_textures = nullptr;
+  uint8_t *d_texels = nullptr;
   uint32_t max_depth = 0, n_meshes = 0;
   uint64_t bytes = 0;
   Plan plan;
@@ -891,7 +927,7 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   Workspace &w = s->ws;
   if (w.cap >= cap) return PT_OK;
   free_workspace(w);
-  const size_t arrays = 2 * 13 + 5 + 3;
+  const size_t arrays = 2 * 13 + 8 + 3;
   const size_t stride = (cap + 63) & ~(size_t)63;
   const size_t n_chunks = stride / 64;
   if ((n_chunks + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock) return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
@@ -907,6 +943,8 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   }
   w.hit.t = take(); w.hit.nx = take(); w.hit.ny = take(); w.hit.nz = take();
   w.hit.mat = reinterpret_cast<uint32_t *>(take());
+  w.hit.u = take(); w.hit.v = take();
+  w.hit.slot = reinterpret_cast<uint32_t *>(take());
   w.Lr = take(); w.Lg = take(); w.Lb = take();
   w.chunk_mask = reinterpret_cast<unsigned long long *>(p);
   w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
@@ -988,7 +1026,9 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
     const Workspace &w = s->ws;
     const uint32_t kRun = run_length(s->plan, n);
     if (!s->plan.split) {
-      auto k = s->plan.resident ? k_shade<MODE, BLOCK, COUNT, true, 0> : k_shade<MODE, BLOCK, COUNT, false, 0>;
+      const bool tex = s->dev.n_tex != 0;
+      auto k = s->plan.resident ? (tex ? k_shade<MODE, BLOCK, COUNT, true, 0, true> : k_shade<MODE, BLOCK, COUNT, true, 0, false>)
+                                : (tex ? k_shade<MODE, BLOCK, COUNT, false, 0, true> : k_shade<MODE, BLOCK, COUNT, false, 0, false>);
       int rc = allow_lds(k, s->plan.lds_bytes);
       if (rc != PT_OK) return rc;
       hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, kRun, F, depth, n, in,
@@ -998,7 +1038,7 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
     }
     // prepare the visibility rays, walk them (with per-lane refill when the scene is outside LDS), finish the vertices
     if ((size_t)n * s->dev.n_lights > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
-    auto ka = k_shade<MODE, BLOCK, COUNT, false, 1>;
+    auto ka = k_shade<MODE, BLOCK, COUNT, false, 1, false>;
     hipLaunchKernelGGL(ka, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
                        w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
     HIP_TRY(hipGetLastError());
@@ -1009,7 +1049,7 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
     hipLaunchKernelGGL(kw, grid_for(s->plan, items), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds,
                        run_length(s->plan, items), n, w.hit, w.sd, s->d_cnt + 5, s->d_stats);
     HIP_TRY(hipGetLastError());
-    auto kb = k_shade<MODE, BLOCK, COUNT, false, 2>;
+    auto kb = s->dev.n_tex != 0 ? k_shade<MODE, BLOCK, COUNT, false, 2, true> : k_shade<MODE, BLOCK, COUNT, false, 2, false>;
     hipLaunchKernelGGL(kb, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
                        w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
     HIP_TRY(hipGetLastError());
@@ -1142,6 +1182,9 @@ void pt_scene_free(PtScene *s) {
   if (s->d_lights) (void)hipFree(s->d_lights);
   if (s->d_ltris) (void)hipFree(s->d_ltris);
   if (s->d_levels) (void)hipFree(s->d_levels);
+  if (s->d_tri_uv) (void)hipFree(s->d_tri_uv);
+  if (s->d_textures) (void)hipFree(s->d_textures);
+  if (s->d_texels) (void)hipFree(s->d_texels);
   if (s->d_spill) (void)hipFree(s->d_spill);
   if (s->d_cnt) (void)hipFree(s->d_cnt);
   if (s->d_stats) (void)hipFree(s->d_stats);
@@ -1167,6 +1210,13 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(up(&s->d_lights, f.lights));
   HIP_TRY(up(&s->d_ltris, f.light_tris));
   HIP_TRY(up(&s->d_levels, f.tri_levels));
+  if (!f.textures.empty()) {
+    HIP_TRY(up(&s->d_tri_uv, f.tri_uv));
+    HIP_TRY(up(&s->d_textures, f.textures));
+    HIP_TRY(up(&s->d_texels, f.texels));
+  }
+  s->dev.tri_uv = s->d_tri_uv; s->dev.textures = s->d_textures; s->dev.texels = s->d_texels;
+  s->dev.n_tex = (uint32_t)f.textures.size();
   HIP_TRY(hipMalloc(&s->d_cnt, 8 * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&s->d_stats, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
@@ -1431,7 +1481,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     if (counters) *counters = c;
     return PT_OK;
   }
-  // samples per pixel in flight together, bounded by memory (about 137 bytes per path)
+  // samples per pixel in flight together, bounded by memory (about 149 bytes per path)
   uint32_t batch = o.batch_spp;
   if (batch == 0) {
     // every batch ends in a long tail of nearly empty passes (half of the 44 passes of a 33-spp
@@ -1440,7 +1490,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     uint64_t target = 192ull << 20;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && s->ws.cap == 0) {
-      const uint64_t fit = (uint64_t)free_b / 4 / 140;
+      const uint64_t fit = (uint64_t)free_b / 4 / 152;
       if (fit < target) target = fit;
     }
     if (s->ws.cap > target) target = s->ws.cap;  // a workspace that exists is used in full

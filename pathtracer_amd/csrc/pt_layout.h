@@ -55,13 +55,19 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
-struct alignas(16) MatRec {  // Material::diffuse / emission, object.cpp:146-148
+struct alignas(16) MatRec {  // Material::diffuse / emission / diffuse_map, object.cpp:146-149
   float kd[3];
-  float pad0;
+  uint32_t tex;  // 0 = no diffuse map, else 1 + index into the texture table
   float ke[3];
   float pad1;
 };
 static_assert(sizeof(MatRec) == 32, "MatRec must be 32 bytes");
+
+// One diffuse map: `width*height` RGB byte triples starting at byte `offset` of the texel table.
+struct alignas(16) TexRec {
+  uint32_t offset, width, height, pad;
+};
+static_assert(sizeof(TexRec) == 16, "TexRec must be 16 bytes");
 
 // One emissive mesh (an entry of Scene::lights(), scene.cpp:22-30).
 struct alignas(16) LightRec {

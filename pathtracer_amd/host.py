@@ -27,6 +27,8 @@ def lib():
         L.pth_scene_from_cache.argtypes = [C.c_char_p]
         L.pth_scene_save_cache.restype = C.c_int
         L.pth_scene_save_cache.argtypes = [C.c_void_p, C.c_char_p]
+        L.pth_load_image.restype = C.c_int
+        L.pth_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
         L.pth_scene_free.argtypes = [C.c_void_p]
         L.pth_scene_free.restype = None
         L.pth_scene_desc.restype = C.POINTER(api.PtSceneDesc)
@@ -123,6 +125,11 @@ class Scene:
             mesh_material=_arr(d.mesh_material, np.uint32, nm),
             materials=_arr(d.materials, api.MAT_DTYPE, d.n_materials),
         )
+        if d.n_textures:
+            recs = C.cast(d.textures, C.POINTER(api.PtTexture * d.n_textures)).contents
+            out["textures"] = [_arr(r.rgb, np.uint8, r.width * r.height * 3).reshape(r.height, r.width, 3) for r in recs]
+            out["material_texture"] = _arr(d.material_texture, np.int32, d.n_materials)
+            out["tri_uv"] = _arr(d.tri_uv, np.float32, nt * 6).reshape(nt, 3, 2)
         lights = np.zeros(nm, np.uint32)
         k = lib().pth_scene_lights(self._h, _p(lights), nm)
         out["lights"] = lights[:k].copy()
@@ -148,6 +155,17 @@ class Scene:
         if rc != 0:
             raise api.PtError(rc, lib().pth_last_error().decode())
         return pixels, cnt
+
+
+def load_image(path):
+    """An image file decoded the way a diffuse map is: [H,W,3] uint8.  PNG (8-bit, non-interlaced) and PPM."""
+    w, h = C.c_uint32(), C.c_uint32()
+    if lib().pth_load_image(os.fsencode(path), C.byref(w), C.byref(h), None, 0) != 0:
+        raise ValueError(lib().pth_last_error().decode())
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    if lib().pth_load_image(os.fsencode(path), C.byref(w), C.byref(h), _p(out), out.size) != 0:
+        raise ValueError(lib().pth_last_error().decode())
+    return out
 
 
 def point_towards(cam, W, H):

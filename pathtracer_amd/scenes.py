@@ -184,6 +184,42 @@ def write_obj(path, meshes, materials):
             base += len(v)
 
 
+def write_textured_obj(path, meshes, materials, textures, planar_axes=(0, 2)):
+    """Like write_obj, with texture coordinates and diffuse maps: `textures` maps a material id to
+    an [H,W,3] uint8 array, written as binary PPM beside the OBJ and named by map_Kd.  Every
+    vertex gets the texture coordinate (p[a] - min_a) / (max_a - min_a) of its own mesh for the two
+    `planar_axes`, so faces use the a/b/c form with b == a."""
+    stem = path[:-4] if path.endswith(".obj") else path
+    with open(stem + ".mtl", "w") as f:
+        for i, (kd, ke) in enumerate(materials):
+            f.write("newmtl m%d\nKd %.6f %.6f %.6f\nKe %.6f %.6f %.6f\n" % ((i,) + tuple(kd) + tuple(ke)))
+            if i in textures:
+                t = np.ascontiguousarray(textures[i], np.uint8)
+                name = "%s_tex%d.ppm" % (stem.split("/")[-1], i)
+                with open(stem.rsplit("/", 1)[0] + "/" + name if "/" in stem else name, "wb") as g:
+                    g.write(b"P6\n%d %d\n255\n" % (t.shape[1], t.shape[0]))
+                    g.write(t.tobytes())
+                f.write("map_Kd %s\n" % name)
+    base = 0
+    with open(path, "w") as f:
+        f.write("mtllib %s\n" % (stem + ".mtl").split("/")[-1])
+        for k, (v, t, m) in enumerate(meshes):
+            f.write("o mesh%d\n" % k)
+            lo, hi = v.min(0), v.max(0)
+            span = np.where(hi > lo, hi - lo, 1.0)
+            for p in v:
+                f.write("v %.6f %.6f %.6f\n" % (p[0], p[1], p[2]))
+            for p in v:
+                q = (p - lo) / span
+                f.write("vt %.6f %.6f\n" % (q[planar_axes[0]], q[planar_axes[1]]))
+            f.write("vn 0.0000 0.0000 1.0000\n")
+            f.write("usemtl m%d\n" % m)
+            for a, b, c in t:
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a + 1 + base, a + 1 + base, k + 1, b + 1 + base, b + 1 + base, k + 1,
+                                                           c + 1 + base, c + 1 + base, k + 1))
+            base += len(v)
+
+
 def round_like_obj(meshes):
     """The vertices write_obj + a correctly rounding parser would give back."""
     out = []

@@ -250,3 +250,133 @@ def test_scene_cache_round_trip_and_rejection(tmp_path):
             host.Scene.from_cache(p)
     with pytest.raises(ValueError):
         host.Scene.from_cache(str(tmp_path / "missing.ptscene"))
+
+
+def _write_png(path, img, color_type, filters, palette=None, alpha=None, level=6):
+    """A PNG written with Python's zlib: img is [H,W] (grey / palette indices) or [H,W,3];
+    `filters` is the filter type of each row (cycled)."""
+    import struct
+    import zlib
+    h, w = img.shape[:2]
+    if color_type == 0 or color_type == 3:
+        px = img.reshape(h, w, 1)
+    elif color_type == 2:
+        px = img
+    elif color_type == 4:
+        px = np.concatenate([img.reshape(h, w, 1), alpha.reshape(h, w, 1)], 2)
+    else:
+        px = np.concatenate([img, alpha.reshape(h, w, 1)], 2)
+    bpp = px.shape[2]
+    rows = px.reshape(h, w * bpp).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * bpp, np.int32)
+    for y in range(h):
+        f = filters[y % len(filters)]
+        cur = rows[y]
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if f == 0:
+            pred = np.zeros_like(cur)
+        elif f == 1:
+            pred = a
+        elif f == 2:
+            pred = prev
+        elif f == 3:
+            pred = (a + prev) // 2
+        else:
+            p = a + prev - c
+            pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw.append(f)
+        raw += bytes(((cur - pred) & 255).astype(np.uint8))
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    z = zlib.compress(bytes(raw), level)
+    body = chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0))
+    if palette is not None:
+        body += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    body += chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + body)
+
+
+@pytest.mark.parametrize("level", [0, 1, 9])
+def test_png_and_ppm_decoders(tmp_path, level):
+    """Diffuse maps: every PNG colour type and row filter, stored / fixed / dynamic deflate blocks,
+    against the pixels that were written; binary and plain PPM; broken files are refused."""
+    rng = np.random.default_rng(level)
+    h, w = 13, 17
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rgb[4:9] = rgb[3]                                  # repeated rows: long matches for the LZ77 side
+    grey = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    alpha = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    pal = rng.integers(0, 256, (200, 3), dtype=np.uint8)
+    idx = rng.integers(0, 200, (h, w), dtype=np.uint8)
+    p = str(tmp_path / "t.png")
+    _write_png(p, rgb, 2, [0, 1, 2, 3, 4], level=level)
+    assert np.array_equal(host.load_image(p), rgb)
+    _write_png(p, rgb, 6, [4, 3, 1], alpha=alpha, level=level)
+    assert np.array_equal(host.load_image(p), rgb)
+    _write_png(p, grey, 0, [2, 4], level=level)
+    assert np.array_equal(host.load_image(p), np.repeat(grey[..., None], 3, 2))
+    _write_png(p, grey, 4, [1, 3], alpha=alpha, level=level)
+    assert np.array_equal(host.load_image(p), np.repeat(grey[..., None], 3, 2))
+    _write_png(p, idx, 3, [0, 4], palette=pal, level=level)
+    assert np.array_equal(host.load_image(p), pal[idx])
+    big = rng.integers(0, 4, (150, 211, 3), dtype=np.uint8) * 60   # compressible: dynamic Huffman, distances > 1 row
+    _write_png(p, big, 2, [4], level=level)
+    assert np.array_equal(host.load_image(p), big)
+    q = str(tmp_path / "t.ppm")
+    open(q, "wb").write(b"P6\n# comment\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+    assert np.array_equal(host.load_image(q), rgb)
+    open(q, "w").write("P3\n%d %d\n255\n" % (w, h) + " ".join(str(int(x)) for x in rgb.ravel()) + "\n")
+    assert np.array_equal(host.load_image(q), rgb)
+    raw = open(p, "rb").read()
+    for bad in (raw[:len(raw) // 2], raw[:40] + bytes([raw[40] ^ 0xff]) + raw[41:], b"GIF89a" + raw[6:]):
+        open(p, "wb").write(bad)
+        try:
+            got = host.load_image(p)
+        except ValueError:
+            continue
+        assert got.shape == big.shape  # a flipped bit may still decode; it must not crash or change the size
+
+
+def test_textured_obj_oracle_and_host_agree(tmp_path):
+    """map_Kd, vt and a/b/c faces: the oracle's regex loader and the host's scanner give the same
+    PtSceneDesc (textures, material_texture, tri_uv included); the cache keeps all of it; and the
+    texel rule of camera.cpp:124-146 on a case worked by hand."""
+    meshes, mats = scenes.box_room(4)
+    rng = np.random.default_rng(1)
+    tex = {0: rng.integers(0, 256, (5, 7, 3), dtype=np.uint8), 2: rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)}
+    p = str(tmp_path / "room.obj")
+    scenes.write_textured_obj(p, meshes, mats, tex)
+    w = O.World.from_obj(p)
+    s = host.Scene.from_obj(p)
+    a, b = w.export(), s.export()
+    c = str(tmp_path / "room.ptscene")
+    s.save_cache(c)
+    e = host.Scene.from_cache(c).export()
+    assert sorted(a) == sorted(b) == sorted(e) and "tri_uv" in a
+    for k in a:
+        if k == "textures":
+            assert len(a[k]) == 2 and all(np.array_equal(x, y) and np.array_equal(x, z) for x, y, z in zip(a[k], b[k], e[k]))
+        else:
+            assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes() == np.asarray(e[k]).tobytes(), k
+    # one triangle, texture coordinates (0,0) (1,0) (1,1), a 2x2 map: u = .5, v = .25 gives
+    # tu = .25*0 + .5*1 + .25*1 = .75, tv = .25 -> texel (x = int(1.5) = 1, y = int(.5) = 0)
+    q = str(tmp_path / "one.obj")
+    t2 = np.array([[[10, 20, 30], [40, 50, 60]], [[70, 80, 90], [100, 110, 120]]], np.uint8)
+    open(str(tmp_path / "one.ppm"), "wb").write(b"P6\n2 2\n255\n" + t2.tobytes())
+    open(str(tmp_path / "one.mtl"), "w").write("newmtl m\nKd 0.5 0.5 0.5\nmap_Kd one.ppm\n")
+    open(q, "w").write("mtllib one.mtl\no tri\nv 0 0 1\nv 1 0 1\nv 1 1 1\nvt 0 0\nvt 1 0\nvt 1 1\nvn 0 0 1\nusemtl m\nf 1/1/1 2/2/1 3/3/1\n")
+    w1 = O.World.from_obj(q)
+    assert np.array_equal(w1.texel(0, 0, 0.5, 0.25), np.array([40, 50, 60], np.float32) / np.float32(255))
+    assert np.array_equal(w1.texel(0, 0, 0.0, 0.999), np.array([100, 110, 120], np.float32) / np.float32(255))  # clamped to the last texel
+    assert O.World.from_obj(str(tmp_path / "room.obj")).texel(3, 0, 0.1, 0.1) is None  # the left wall has no map
+    # a textured object whose faces carry no texture coordinate is an error, not a crash (object.cpp:542-553 asserts)
+    open(q, "w").write("mtllib one.mtl\no tri\nv 0 0 1\nv 1 0 1\nv 1 1 1\nvn 0 0 1\nusemtl m\nf 1//1 2//1 3//1\n")
+    with pytest.raises(ValueError):
+        host.Scene.from_obj(q)
+    with pytest.raises(Exception):
+        O.World.from_obj(q)
