@@ -321,11 +321,12 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, RayState &st, V3 o,
 }
 
 // One round for the wave: a node step for every lane that has one, then — when enough lanes
-// hold a parked leaf or no lane has node work — the triangle tests of the parked leaves.
+// hold a parked leaf (`quorum` of them for a closest-hit walk) or no lane has node work — the
+// triangle tests of the parked leaves.
 // Lanes whose state is done() do nothing.
 template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES>
 __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
-                                           uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris) {
+                                           uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
   if (st.live && !(st.cur & ptl::REF_LEAF)) {
     float4 q0, q1, q2;
     uint4 q3;
@@ -396,7 +397,7 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   // inside the light loop of the shading kernel with whatever lanes hit something
   bool enough;
   if (ANY) enough = (uint32_t)__popcll(m_pend) * 64u >= S.quorum_any * (uint32_t)__popcll(__ballot(!st.done()));
-  else enough = (uint32_t)__popcll(m_pend) >= S.quorum;
+  else enough = (uint32_t)__popcll(m_pend) >= quorum;
   if (enough || m_node == 0) {
     if (st.pend != 0) {
       const uint32_t first = st.pend & ptl::REF_FIRST_MASK;
@@ -458,7 +459,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
   RayState st;
   walk_init<MODE, WANT_N>(S, st, o, d);
   do {
-    walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris);
+    walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, S.quorum);
   } while (__ballot(!st.done()) != 0);
   best = st.best;
   return ANY ? st.found : st.best.slot != 0xffffffffu;

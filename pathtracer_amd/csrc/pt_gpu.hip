@@ -202,10 +202,10 @@ __device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
 // Each lane carries its own ray; when S.refill lanes are idle the wave stores their results and
 // hands them the next items of the run of chunks it has claimed, claiming another run when that
 // one is used up (1.8 times the rays per second on a 260 k-triangle scene).
-template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES, int BLOCK, typename Fetch, typename Retire>
+template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES, bool REFILL, int BLOCK, typename Fetch, typename Retire>
 __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C, uint32_t stk, uint64_t n, uint32_t kRun,
                                            uint32_t *head, uint32_t &nb, uint32_t &nt, Fetch fetch, Retire retire) {
-  if constexpr (RES) {
+  if constexpr (!REFILL) {
     const uint32_t lane = threadIdx.x & 63;
     for (;;) {
       const uint32_t run = next_run(head, kRun);
@@ -219,7 +219,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
           RayState st;
           walk_init<MODE, WANT_N>(S, st, o, d);
           do {
-            walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt);
+            walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, S.quorum);
           } while (__ballot(!st.done()) != 0);
           retire(i, st);
         }
@@ -238,6 +238,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
       const unsigned long long m_busy = __ballot(busy);
       const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
       const bool can_fetch = more || pool < pool_end;
+      uint32_t n_idle_now = n_idle;
       if ((n_idle >= S.refill && can_fetch) || m_busy == 0) {
         if (!busy && mine != NONE) {
           retire(mine, st);
@@ -265,12 +266,15 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
           }
         }
         pool = pool_end - pool > n_idle ? pool + n_idle : pool_end;
-        if (__ballot(busy) == 0) {
+        const unsigned long long m_now = __ballot(busy);
+        if (m_now == 0) {
           if (!more && pool >= pool_end) break;
           continue;  // nothing to walk among these items, or the run is used up: fetch again
         }
+        n_idle_now = 64u - (uint32_t)__popcll(m_now);
       }
-      walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt);
+      // the quorum for testing parked leaves counts against the lanes that have a ray at all
+      walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, ((64u - n_idle_now) * S.quorum) >> 6);
       if (busy && st.done()) busy = false;
     }
   }
@@ -294,14 +298,14 @@ __device__ __forceinline__ bool survives(const SceneDev &S, const FrameDev &F, i
 // vertex and leaves that as one byte per ray in `alive_out`, from which k_scan_local forms the
 // 64-bit mask of each chunk, so that the survivors' places in the next queue are known before
 // the shading kernel writes them.
-template <int MODE, int BLOCK, bool COUNT, bool RES>
+template <int MODE, int BLOCK, bool COUNT, bool RES, bool REFILL>
 __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth,
                                                        uint32_t n, QueueDev q, HitDev hit, uint8_t *alive_out,
                                                        uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
-  walk_items<MODE, false, COUNT, true, RES, BLOCK>(
+  walk_items<MODE, false, COUNT, true, RES, REFILL, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
         o = mk(q.ox[i], q.oy[i], q.oz[i]);
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, u
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
-  walk_items<MODE, false, COUNT, false, RES, BLOCK>(
+  walk_items<MODE, false, COUNT, false, RES, !RES, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
         o = mk(ox[i], oy[i], oz[i]);
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uin
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
-  walk_items<MODE, true, false, false, RES, BLOCK>(
+  walk_items<MODE, true, false, false, RES, !RES, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
         o = mk(ox[i], oy[i], oz[i]);
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, ui
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
-  walk_items<MODE, false, false, false, RES, BLOCK>(
+  walk_items<MODE, false, false, false, RES, !RES, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
         o = mk(ox[i], oy[i], oz[i]);
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_walk(SceneDev S, LdsPlan plan,
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
-  walk_items<MODE, true, COUNT, false, RES, BLOCK>(
+  walk_items<MODE, true, COUNT, false, RES, !RES, BLOCK>(
       S, C, stk, (uint64_t)n * S.n_lights, kRun, head, nb, nt,
       [&](uint64_t k, V3 &o, V3 &d) {
         const uint32_t i = (uint32_t)(k % n);
@@ -813,6 +817,7 @@ struct Plan {
   unsigned max_blocks = 0;  // workgroups the chip keeps resident
   bool resident = false;    // all nodes, all triangles and the whole stack are in LDS
   bool split = false;       // shading runs as three kernels (visibility rays walked on their own)
+  bool refill_resident = false;  // closest-hit kernel hands out rays lane by lane even when the scene is in LDS
 };
 
 struct PtScene {
@@ -904,6 +909,7 @@ static int make_plan(PtScene *s) {
   p.resident = p.lds.n_nodes == s->dev.n_nodes && p.lds.n_tris == s->dev.n_tris && s->max_depth <= (uint32_t)p.stack &&
                !std::getenv("PT_NO_RESIDENT");
   p.split = !p.resident;
+  if (const char *e = std::getenv("PT_RES_REFILL")) p.refill_resident = std::atoi(e) != 0;  // tuning knob
   if (const char *e = std::getenv("PT_SPLIT")) p.split = std::atoi(e) != 0;  // tuning knob
   if (std::getenv("PT_VERBOSE"))
     std::fprintf(stderr, "ptgpu plan: depth %u, block %d, LDS stack %d entries/lane, %u nodes + %u triangles in LDS, %zu B LDS per workgroup, %u resident workgroups\n",
@@ -1008,7 +1014,8 @@ template <int MODE, bool COUNT>
 static int launch_trace_queue(PtScene *s, const FrameDev &F, int depth, uint32_t n, const QueueDev &q, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = s->plan.resident ? k_trace_queue<MODE, BLOCK, COUNT, true> : k_trace_queue<MODE, BLOCK, COUNT, false>;
+    auto k = !s->plan.resident ? k_trace_queue<MODE, BLOCK, COUNT, false, true>
+             : s->plan.refill_resident ? k_trace_queue<MODE, BLOCK, COUNT, true, true> : k_trace_queue<MODE, BLOCK, COUNT, true, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n, q,
