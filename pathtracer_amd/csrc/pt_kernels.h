@@ -1,0 +1,763 @@
+// pt_kernels.h — the gfx950 kernels of the render hot path (included once, by pt_gpu.hip, which
+// holds the launch code and the C ABI).  Wavefront organisation: every stage is its own kernel
+// over a structure-of-arrays queue of live paths; one lane carries one ray.
+#ifndef PT_KERNELS_H
+#define PT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "pt_device.h"
+
+using namespace ptd;
+
+
+
+static const int kBlock = 256;  // block size of the streaming kernels (ray generation, resolve)
+static const int kScanBlock = 1024;
+static const int kScanPer = 4;
+static const int kScanSpan = kScanBlock * kScanPer;  // chunks one workgroup of k_scan_local covers
+
+struct QueueDev {  // one live path per index, arrays `cap` long
+  float *ox, *oy, *oz, *dx, *dy, *dz;  // ray
+  float *tx, *ty, *tz;                 // throughput
+  float *lx, *ly, *lz;                 // radiance gathered so far
+  uint32_t *id;                        // sample_in_batch * P + pixel
+};
+
+struct HitDev {  // closest hit of every queued ray
+  float *t;
+  float *nx, *ny, *nz;  // Triangle::normal() of the hit triangle, un-normalised
+  uint32_t *mat;
+  float *u, *v;         // barycentrics and triangle record of the hit: written and read only when
+  uint32_t *slot;       // the scene has a textured material
+};
+
+struct FrameDev {
+  int W, H;
+  uint32_t P;            // W*H
+  float origin[3];
+  double rot[9];         // rotate() coefficients, math.cpp:130-140, row-major
+  float vw, neg_vh;      // (float)vw, (float)(-vh)
+  float pin_z;           // third component of point_towards before the rotation
+  float aperture, focus;
+  uint64_t seed;
+  uint32_t sample0;      // global index of the batch's first sample
+  uint32_t stride;       // distance between consecutive samples' global indices
+  float rr_prob;
+  int rr_min_depth, max_depth, sampling;
+  float bg[3];
+  float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
+  float pi_f;            // (float)M_PI, camera.cpp:122
+  uint32_t dims_per_vertex;
+};
+
+// What a traversal kernel keeps in LDS (see LdsScene) and how many words of the
+// per-launch counter block it uses as its work-queue head.
+struct LdsPlan {
+  uint32_t n_nodes;    // top nodes staged in LDS
+  uint32_t n_tris;     // 0, or all triangles
+  uint32_t stack_lds;  // stack entries per lane kept in LDS
+  uint32_t *spill;     // global spill area for deeper stacks (null when none is needed)
+};
+
+__device__ __forceinline__ V3 rotate9(const double *c, V3 p) {
+  const double px = p.x, py = p.y, pz = p.z;
+  V3 r;
+  r.x = (float)((c[0] * px) + (c[1] * py) + (c[2] * pz));
+  r.y = (float)((c[3] * px) + (c[4] * py) + (c[5] * pz));
+  r.z = (float)((c[6] * px) + (c[7] * py) + (c[8] * pz));
+  return r;
+}
+
+__device__ __forceinline__ void camera_ray(const FrameDev &F, int px, int py, PathRng &rng, V3 &o, V3 &d) {
+  // camera.cpp:162-167: float arithmetic on x and y, z prepared in double by the host
+  const float x = ((float)px - (float)F.W / 2) * F.vw / (float)F.W;
+  const float y = ((float)py - (float)F.H / 2) * F.neg_vh / (float)F.H;
+  const V3 dc = mk(x, y, F.pin_z);
+  if (F.aperture > 0.0f) {  // thin lens: not in the reference
+    const float u1 = rng.real(0.0f, 1.0f, 0), u2 = rng.real(0.0f, 1.0f, 1);
+    const float r = F.aperture * sqrtf(u1);
+    const double ph = 2 * M_PI * (double)u2;
+    const V3 lens = mk((float)(cos(ph) * (double)r), (float)(sin(ph) * (double)r), 0.0f);
+    const float s = F.focus / dc.z;
+    const V3 pf = scale(dc, s);
+    const float inv_s = dc.z / F.focus;
+    const V3 dl = scale(sub(pf, lens), inv_s);
+    o = add(mk(F.origin[0], F.origin[1], F.origin[2]), rotate9(F.rot, lens));
+    d = rotate9(F.rot, dl);
+  } else {
+    o = mk(F.origin[0], F.origin[1], F.origin[2]);
+    d = rotate9(F.rot, dc);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_raygen(FrameDev F, uint32_t n, QueueDev q) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = i / F.P, p = i - s * F.P;
+  const int py = (int)(p / (uint32_t)F.W), px = (int)(p - (uint32_t)py * (uint32_t)F.W);
+  PathRng rng;
+  rng.init(F.seed, p, F.sample0 + s * F.stride);
+  V3 o, d;
+  camera_ray(F, px, py, rng, o, d);
+  q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
+  q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
+  q.tx[i] = 1.0f; q.ty[i] = 1.0f; q.tz[i] = 1.0f;
+  q.lx[i] = 0.0f; q.ly[i] = 0.0f; q.lz[i] = 0.0f;
+  q.id[i] = i;
+}
+
+// Camera::point_towards for every pixel, for callers that only want the directions.
+__global__ __launch_bounds__(kBlock) void k_camera_dirs(FrameDev F, float *dir) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= F.P) return;
+  const int py = (int)(p / (uint32_t)F.W), px = (int)(p - (uint32_t)py * (uint32_t)F.W);
+  PathRng rng;
+  rng.init(F.seed, p, 0);
+  FrameDev G = F;
+  G.aperture = 0.0f;
+  V3 o, d;
+  camera_ray(G, px, py, rng, o, d);
+  dir[3 * (size_t)p + 0] = d.x;
+  dir[3 * (size_t)p + 1] = d.y;
+  dir[3 * (size_t)p + 2] = d.z;
+}
+
+__device__ __forceinline__ void wave_add64(unsigned long long *dst, uint32_t v) {
+  uint32_t s = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, (unsigned long long)s);
+}
+
+// The traversal kernels are persistent: a launch holds at most as many workgroups as the
+// chip keeps resident, every workgroup stages its part of the scene into LDS once, and
+// every wave then pulls chunks of 64 rays from a shared counter until none are left.
+
+// The LDS copy is split by quarter: quarter k of node i sits at nodes[k*n_nodes + i] (and
+// third k of triangle i at tris[k*n_tris + i]).  A wave's 64 lanes then read 16-byte pieces
+// whose bank depends on i mod 16; with whole 64-byte records side by side only 4 of the 16
+// bank groups would ever be hit by one instruction.
+template <int BLOCK>
+__device__ __forceinline__ LdsScene stage_scene(const SceneDev &S, LdsPlan plan, uint32_t &stack_base) {
+  const float4 *gn = reinterpret_cast<const float4 *>(S.nodes);
+  const float4 *gt = reinterpret_cast<const float4 *>(S.tris);
+  LdsScene C;
+  C.node_base = 0;
+  C.tri_base = 4u * plan.n_nodes;
+  C.n_nodes = plan.n_nodes;
+  C.n_tris = plan.n_tris;
+  C.stack_lds = plan.stack_lds;
+  C.spill_stride = gridDim.x * BLOCK;
+  C.spill = plan.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  for (uint32_t i = threadIdx.x; i < 4u * plan.n_nodes; i += BLOCK) pt_smem[(i & 3u) * plan.n_nodes + (i >> 2)] = gn[i];
+  for (uint32_t i = threadIdx.x; i < 3u * plan.n_tris; i += BLOCK)
+    pt_smem[C.tri_base + (i % 3u) * plan.n_tris + (i / 3u)] = gt[i];
+  __syncthreads();
+  stack_base = 4u * (C.tri_base + 3u * plan.n_tris) + threadIdx.x;  // in 32-bit words
+  return C;
+}
+
+// Work is claimed in runs of `len` chunks of 64 items.  One returning atomic on a single
+// word sustains under 100 claims per microsecond chip-wide, so a claim per 64 rays would cap
+// a large launch at about 6 G rays/s on its own; a long run, on the other hand, serialises a
+// small launch on few waves.  The host picks `len` per launch (run_length()).
+// Returns the first chunk of the next run for this wave (all lanes must be active).
+__device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
+  uint32_t c = 0;
+  if ((threadIdx.x & 63) == 0) c = atomicAdd(head, len);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+}
+
+// Walks one ray per work item for items [0, n), persistent over the whole launch.
+//   fetch(i, o, d)  loads item i's ray; returns false when the item needs no walk (it then has
+//                   written whatever the item's output is);
+//   retire(i, st)   stores the result of a walked item.
+//
+// RES (scene in LDS): walks are short and cost no memory latency; a wave walks whole chunks of 64
+// items, all lanes together.  Handing out items lane by lane was measured slower there: its
+// bookkeeping runs with few lanes active.
+// Otherwise rays differ widely in the number of steps and every step waits on memory, so a wave
+// does not walk 64 rays in lockstep until the slowest is done (measured: 42 % of the lanes active).
+// Each lane carries its own ray; when S.refill lanes are idle the wave stores their results and
+// hands them the next items of the run of chunks it has claimed, claiming another run when that
+// one is used up (1.8 times the rays per second on a 260 k-triangle scene).
+template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES, bool REFILL, int BLOCK, typename Fetch, typename Retire>
+__device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C, uint32_t stk, uint64_t n, uint32_t kRun,
+                                           uint32_t *head, uint32_t &nb, uint32_t &nt, Fetch fetch, Retire retire) {
+  if constexpr (!REFILL) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+      const uint32_t run = next_run(head, kRun);
+      if ((uint64_t)run * 64u >= n) break;
+      for (uint32_t c = 0; c < kRun; ++c) {
+        const uint64_t base = ((uint64_t)run + c) * 64u;
+        if (base >= n) break;
+        const uint64_t i = base + lane;
+        V3 o, d;
+        if (i < n && fetch(i, o, d)) {
+          RayState st;
+          walk_init<MODE, WANT_N>(S, st, o, d);
+          do {
+            walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, S.quorum);
+          } while (__ballot(!st.done()) != 0);
+          retire(i, st);
+        }
+      }
+    }
+  } else {
+    uint64_t pool = 0, pool_end = 0;  // items of the claimed run not handed out yet (same in all lanes)
+    bool more = true;                 // the queue may hold further runs
+    const uint64_t NONE = ~0ull;
+    uint64_t mine = NONE;             // item this lane works on or has finished
+    bool busy = false;
+    RayState st;
+    st.live = false;
+    st.pend = 0;
+    for (;;) {
+      const unsigned long long m_busy = __ballot(busy);
+      const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
+      const bool can_fetch = more || pool < pool_end;
+      uint32_t n_idle_now = n_idle;
+      if ((n_idle >= S.refill && can_fetch) || m_busy == 0) {
+        if (!busy && mine != NONE) {
+          retire(mine, st);
+          mine = NONE;
+        }
+        if (pool >= pool_end && more) {
+          const uint32_t run = next_run(head, kRun);
+          if ((uint64_t)run * 64u >= n) {
+            more = false;
+          } else {
+            pool = (uint64_t)run * 64u;
+            const uint64_t e = ((uint64_t)run + kRun) * 64u;
+            pool_end = e < n ? e : n;
+          }
+        }
+        if (!busy) {
+          const unsigned long long idle = ~m_busy;
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+          const uint64_t i = pool + rank;
+          V3 o, d;
+          if (i < pool_end && fetch(i, o, d)) {
+            walk_init<MODE, WANT_N>(S, st, o, d);
+            mine = i;
+            busy = true;
+          }
+        }
+        pool = pool_end - pool > n_idle ? pool + n_idle : pool_end;
+        const unsigned long long m_now = __ballot(busy);
+        if (m_now == 0) {
+          if (!more && pool >= pool_end) break;
+          continue;  // nothing to walk among these items, or the run is used up: fetch again
+        }
+        n_idle_now = 64u - (uint32_t)__popcll(m_now);
+      }
+      // the quorum for testing parked leaves counts against the lanes that have a ray at all
+      walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, ((64u - n_idle_now) * S.quorum) >> 6);
+      if (busy && st.done()) busy = false;
+    }
+  }
+}
+
+// Does the path of queue entry i go on after a vertex whose closest hit is at t?  It does iff it
+// hit something and passes Russian roulette (camera.cpp:65, 118-119).
+__device__ __forceinline__ bool survives(const SceneDev &S, const FrameDev &F, int depth, const QueueDev &q, uint32_t i,
+                                         float t) {
+  if (t == __builtin_inff()) return false;
+  if (F.max_depth > 0 && depth >= F.max_depth) return false;
+  if (depth <= F.rr_min_depth) return true;  // the roulette draw exists only when depth > rr_min_depth
+  const uint32_t id = q.id[i];
+  PathRng rng;
+  rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
+  const uint32_t dim = 2u + (uint32_t)depth * F.dims_per_vertex + 3u * S.n_lights;
+  return (double)rng.real(0.0f, 1.0f, dim) < (double)F.rr_prob;
+}
+
+// Closest hit for every queued ray.  The kernel also decides which paths go on after this
+// vertex and leaves that as one byte per ray in `alive_out`, from which k_scan_local forms the
+// 64-bit mask of each chunk, so that the survivors' places in the next queue are known before
+// the shading kernel writes them.
+template <int MODE, int BLOCK, bool COUNT, bool RES, bool REFILL>
+__global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth,
+                                                       uint32_t n, QueueDev q, HitDev hit, uint8_t *alive_out,
+                                                       uint32_t *head, unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, false, COUNT, true, RES, REFILL, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(q.ox[i], q.oy[i], q.oz[i]);
+        d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) {
+        const HitRec &h = st.best;
+        hit.t[i] = h.t;
+        hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
+        hit.mat[i] = h.mat;
+        if (S.n_tex) {
+          hit.u[i] = h.u; hit.v[i] = h.v;
+          hit.slot[i] = h.slot;
+        }
+        alive_out[i] = survives(S, F, depth, q, (uint32_t)i, h.t) ? 1 : 0;
+      });
+  if (COUNT) {
+    wave_add64(stats + 0, nb);
+    wave_add64(stats + 1, nt);
+  }
+}
+
+template <int MODE, int BLOCK, bool COUNT, bool RES>
+__global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
+                                                     const float *oy, const float *oz, const float *dx,
+                                                     const float *dy, const float *dz, float *t, int32_t *tri,
+                                                     float *u, float *v, uint32_t *head, unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, false, COUNT, false, RES, !RES, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(ox[i], oy[i], oz[i]);
+        d = mk(dx[i], dy[i], dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) {
+        const HitRec &h = st.best;
+        t[i] = h.t;
+        tri[i] = h.slot != 0xffffffffu ? (int32_t)S.tris[h.slot].tri_id : -1;
+        if (u) u[i] = h.u;
+        if (v) v[i] = h.v;
+      });
+  if (COUNT) {
+    wave_add64(stats + 0, nb);
+    wave_add64(stats + 1, nt);
+  }
+}
+
+template <int MODE, int BLOCK, bool RES>
+__global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
+                                                   const float *oy, const float *oz, const float *dx, const float *dy,
+                                                   const float *dz, uint8_t *hit, uint32_t *head) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, true, false, false, RES, !RES, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(ox[i], oy[i], oz[i]);
+        d = mk(dx[i], dy[i], dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) { hit[i] = st.found ? 1 : 0; });
+}
+
+// HitData::hits (object.cpp:203, 281-282: "for special visualizations"): every internal node on
+// the way back up from the winning triangle adds one, so for a hit it is the number of internal
+// nodes of the reference between the root and the triangle's leaf (levels[slot], counted by the
+// flattener).  For a miss the recursion hands up the right child's empty result at every internal
+// node whose box the ray passes (`lhit.t < rhit.t ? lhit : rhit` with both infinite), and the
+// first mesh's result in a top-level leaf: the count is the length of that chain.
+__device__ __forceinline__ bool box_pass_exact(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, V3 d) {
+  const float nan = __builtin_nanf("");
+  const float ix = d.x != 0.0f ? 1.0f / d.x : nan, iy = d.y != 0.0f ? 1.0f / d.y : nan, iz = d.z != 0.0f ? 1.0f / d.z : nan;
+  const float ax = ((ix < 0.0f ? hx : lx) - o.x) * ix, bx = ((ix < 0.0f ? lx : hx) - o.x) * ix;
+  const float ay = ((iy < 0.0f ? hy : ly) - o.y) * iy, by = ((iy < 0.0f ? ly : hy) - o.y) * iy;
+  const float az = ((iz < 0.0f ? hz : lz) - o.z) * iz, bz = ((iz < 0.0f ? lz : hz) - o.z) * iz;
+  const float tn = fmaxf(fmaxf(fmaxf(1e-5f, ax), ay), az);
+  const float tf = fminf(fminf(fminf(__builtin_inff(), bx), by), bz);
+  return tf >= tn;  // the same planes, operations and NaN behaviour as the node step of the exact walk
+}
+
+__device__ __forceinline__ int32_t miss_chain_hits(const SceneDev &S, V3 o, V3 d) {
+  const float4 *nodes = reinterpret_cast<const float4 *>(S.nodes);
+  // node 0 is the super-root: its child 0 is the reference's root
+  float4 q0 = nodes[0], q1 = nodes[1], q2 = nodes[2], q3 = nodes[3];
+  uint32_t kind = __float_as_uint(q3.z), ref = __float_as_uint(q3.x);
+  float lx = q0.x, ly = q0.y, lz = q0.z, hx = q0.w, hy = q1.x, hz = q1.y;
+  int32_t hits = 0;
+  for (;;) {
+    if (kind == KIND_INTERNAL) {
+      if (!box_pass_exact(lx, ly, lz, hx, hy, hz, o, d)) break;
+      ++hits;
+    } else if (kind != KIND_GROUP) {
+      break;  // a leaf of the reference (whole or split): its empty result carries 0
+    }
+    const size_t at = 4u * (size_t)ref;
+    q1 = nodes[at + 1]; q2 = nodes[at + 2]; q3 = nodes[at + 3];
+    kind = __float_as_uint(q3.w); ref = __float_as_uint(q3.y);  // child 1: the right child / the first mesh
+    lx = q1.z; ly = q1.w; lz = q2.x; hx = q2.y; hy = q2.z; hz = q2.w;
+  }
+  return hits;
+}
+
+template <int MODE, int BLOCK, bool RES>
+__global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
+                                                    const float *oy, const float *oz, const float *dx, const float *dy,
+                                                    const float *dz, const uint8_t *levels, int32_t *hits,
+                                                    uint32_t *head) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, false, false, false, RES, !RES, BLOCK>(
+      S, C, stk, n, kRun, head, nb, nt,
+      [&](uint64_t i, V3 &o, V3 &d) {
+        o = mk(ox[i], oy[i], oz[i]);
+        d = mk(dx[i], dy[i], dz[i]);
+        return true;
+      },
+      [&](uint64_t i, const RayState &st) {
+        hits[i] = st.best.slot != 0xffffffffu ? (int32_t)levels[st.best.slot] : miss_chain_hits(S, st.o, st.d);
+      });
+}
+
+// Visibility rays of the split shading pipeline (scenes outside LDS): item k = l*n + i is the
+// ray from vertex i towards its sample of light l, prepared by k_shade<..., 1>.
+struct ShadowDev {
+  float *x, *y, *z;        // per vertex: hit point
+  float *tx, *ty, *tz;     // per item: direction towards the light sample
+  float *wx, *wy, *wz;     // per item: what the light adds if the ray hits anything (camera.cpp:101-114)
+  uint8_t *vis;            // per item: the ray hit something
+};
+
+template <int MODE, int BLOCK, bool COUNT, bool RES>
+__global__ __launch_bounds__(BLOCK) void k_shadow_walk(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, HitDev hit,
+                                                       ShadowDev sd, uint32_t *head, unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  uint32_t nb = 0, nt = 0;
+  walk_items<MODE, true, COUNT, false, RES, !RES, BLOCK>(
+      S, C, stk, (uint64_t)n * S.n_lights, kRun, head, nb, nt,
+      [&](uint64_t k, V3 &o, V3 &d) {
+        const uint32_t i = (uint32_t)(k % n);
+        if (hit.t[i] == __builtin_inff()) return false;  // no vertex, no light loop: nobody reads vis[k]
+        o = mk(sd.x[i], sd.y[i], sd.z[i]);
+        d = mk(sd.tx[k], sd.ty[k], sd.tz[k]);
+        return true;
+      },
+      [&](uint64_t k, const RayState &st) { sd.vis[k] = st.found ? 1 : 0; });
+  if (COUNT) {
+    wave_add64(stats + 2, nb);
+    wave_add64(stats + 3, nt);
+  }
+}
+
+// random_direction, camera.cpp:77-90
+__device__ __forceinline__ V3 uniform_dir(V3 n, float x, float y) {
+  const float phi = 1.0f - 2.0f * x;
+  const float theta = (float)fmax(0.0, (double)(1.0f - phi * phi));
+  const float st = sqrtf(theta);
+  const double ang = 2 * M_PI * (double)y;
+  V3 v = mk((float)(cos(ang) * (double)st), (float)(sin(ang) * (double)st), phi);
+  v = normalize(v);
+  return dot(v, n) < 0.0f ? neg(v) : v;
+}
+// cosine-weighted direction about n: not in the reference
+__device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
+  const float r = sqrtf(x);
+  const float lz = sqrtf(fmaxf(0.0f, 1.0f - x));
+  const double ang = 2 * M_PI * (double)y;
+  const float lx = (float)(cos(ang) * (double)r), ly = (float)(sin(ang) * (double)r);
+  const float s = copysignf(1.0f, n.z);
+  const float a = -1.0f / (s + n.z);
+  const float b = n.x * n.y * a;
+  const V3 t1 = mk(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
+  const V3 t2 = mk(b, s + n.y * n.y * a, -n.y);
+  return add(add(scale(t1, lx), scale(t2, ly)), scale(n, lz));
+}
+
+// static_cast<int>(float) as the reference's x86-64 build performs it (cvttss2si): out of range
+// and NaN give INT_MIN.
+__device__ __forceinline__ int cvt_int_x86(float f) {
+  return (f >= 2147483648.0f || f < -2147483648.0f || f != f) ? (int)0x80000000 : (int)f;
+}
+
+// brdf of a vertex on a textured triangle, camera.cpp:124-146: texture coordinates interpolated
+// with alpha = 1-u-v on vt0, beta = u on vt1, gamma = v on vt2 (HitData::barycentric is
+// (u, v, 1-u-v), object.cpp:428), nearest texel, no flip, the texel itself (no 1/pi).
+__device__ __forceinline__ V3 texel_brdf(const SceneDev &S, uint32_t tex, uint32_t slot, float bu, float bv) {
+  const float *uv = S.tri_uv + (size_t)slot * 6;
+  const float beta = bu, gamma = bv, alpha = 1 - bu - bv;
+  const float tu = alpha * uv[0] + beta * uv[2] + gamma * uv[4];
+  const float tv = alpha * uv[1] + beta * uv[3] + gamma * uv[5];
+  const ptl::TexRec tr = S.textures[tex - 1u];
+  const int w = (int)tr.width, h = (int)tr.height;
+  int x = cvt_int_x86(tu * (float)w), y = cvt_int_x86(tv * (float)h);
+  x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);  // std::clamp
+  y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+  const uint8_t *px = S.texels + tr.offset + ((size_t)y * (size_t)w + (size_t)x) * 3;
+  return divs(mk((float)px[0], (float)px[1], (float)px[2]), 255.0f);  // Image::at, object.cpp:128-134
+}
+
+// One light of the direct-light loop (camera.cpp:96-115) for the vertex at x with shading normal
+// nrm: the direction `to` of the visibility ray and `w`, what the light adds to the vertex if that
+// ray hits anything (the reference adds it when the ray hits *something*, camera.cpp:101-102).
+__device__ __forceinline__ void sample_light(const SceneDev &S, PathRng &rng, uint32_t base, uint32_t l, V3 x,
+                                             V3 nrm, V3 &to, V3 &w) {
+  const float4 *lp = reinterpret_cast<const float4 *>(S.lights + l);
+  const float4 l0 = lp[0], l1 = lp[1];
+  const uint32_t first = __float_as_uint(l0.x), count = __float_as_uint(l0.y);
+  const float area_f = l0.z, inv_area_f = l0.w;
+  const V3 lke = mk(l1.x, l1.y, l1.z);
+  // Polygon::sample, object.cpp:513-523: first triangle whose running area reaches r
+  const double r = (double)rng.real(0.0f, area_f, base + 3u * l);
+  uint32_t lo = 0, hi = count - 1;  // past the end the reference is undefined; take the last
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (r <= S.light_tris[first + mid].accum) hi = mid; else lo = mid + 1;
+  }
+  const float4 *qp = reinterpret_cast<const float4 *>(S.light_tris + first + lo);
+  const float4 g0 = qp[0], g1 = qp[1], g2 = qp[2];
+  const V3 lu = mk(g0.x, g0.y, g0.z), lv = mk(g0.w, g1.x, g1.y), ln = mk(g1.z, g1.w, g2.x);
+  // Triangle::sample, object.cpp:432-442 (the point is relative to v0; v0 is not added)
+  const double s = (double)rng.real(0.0f, 1.0f, base + 3u * l + 1u);
+  const double tt = (double)rng.real(0.0f, 1.0f, base + 3u * l + 2u);
+  V3 point;
+  if (s + tt <= 1.0) point = add(scale(lu, (float)s), scale(lv, (float)tt));
+  else point = add(scale(lu, (float)(1.0 - s)), scale(lv, (float)(1.0 - tt)));
+  to = normalize(sub(point, x));
+  float c = dot(to, nrm);
+  if (c < 0.0f) c = 0.0f;
+  float y = dot(to, ln);
+  if (y < 0.0f) y = 0.0f;
+  const double nn = (double)norm(to);
+  y = (float)((double)y / (nn * nn));  // std::pow(norm, 2) in double, camera.cpp:111
+  w = scale(scale(scale(lke, c), y), inv_area_f);
+}
+
+// One path vertex per work item.  Which paths survive was decided by k_trace_queue and
+// prefix-summed by k_scan_*, so a survivor is written straight to its place in `out`: chunk
+// offset + its rank among the chunk's survivors (wave ballot mask + popcount).
+// The compaction is stable: the queue stays in pixel order and no two launches differ.
+// Claiming an output slot per wave with an atomic on one counter instead was measured at
+// 260 ms per frame on its own: a single word takes under 100 atomics per microsecond.
+// cnt[1] = paths that hit something, cnt[3] / cnt[4] = this kernel's work-queue head (phase 1: cnt[4]).
+//
+// PHASE 0: the whole vertex in one kernel, visibility rays walked in place (scenes in LDS).
+// PHASE 1 / 2 (scenes outside LDS): 1 prepares the visibility rays of every vertex and light
+// (ShadowDev), k_shadow_walk walks them with per-lane refill, 2 does the rest of the vertex
+// with the answers.  The weights w are added in light order in both forms, so the sums agree
+// bit for bit.  TEX: the scene has a diffuse map (untextured scenes run without that code).
+template <int MODE, int BLOCK, bool COUNT, bool RES, int PHASE, bool TEX>
+__global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth, uint32_t n,
+                                                 QueueDev in, HitDev hit, QueueDev out, ShadowDev sd,
+                                                 const unsigned long long *chunk_mask, const uint32_t *chunk_base,
+                                                 const uint32_t *block_off, uint32_t *cnt, float *Lr, float *Lg,
+                                                 float *Lb, unsigned long long *stats) {
+  uint32_t stk = 0;
+  LdsScene C{};
+  if constexpr (PHASE == 0) C = stage_scene<BLOCK>(S, plan, stk);
+  const int lane = threadIdx.x & 63;
+  uint32_t nb = 0, nt = 0, n_hit = 0;
+  uint32_t *head = cnt + (PHASE == 1 ? 4 : 3);
+  for (uint32_t run = next_run(head, kRun), c = 0;; ++c) {
+    if (c == kRun) {
+      run = next_run(head, kRun);
+      c = 0;
+    }
+    const uint32_t first_item = (run + c) * 64u;
+    if ((uint64_t)(run + c) * 64u >= n) break;
+    const uint32_t i = first_item + (uint32_t)lane;
+    const bool active = i < n;
+    const unsigned long long m = PHASE == 1 ? 0ull : chunk_mask[run + c];
+    const bool cont = (m >> lane) & 1ull;  // this path goes on (decided with the closest hit)
+    bool alive = false, did_hit = false;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
+    uint32_t id = 0;
+    if (active) {
+      id = in.id[i];
+      const float t = hit.t[i];
+      if (PHASE != 1) {
+        T = mk(in.tx[i], in.ty[i], in.tz[i]);
+        L = mk(in.lx[i], in.ly[i], in.lz[i]);
+      }
+      if (t == __builtin_inff()) {  // camera.cpp:65-66
+        L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
+      } else {
+        did_hit = true;
+        o = mk(in.ox[i], in.oy[i], in.oz[i]);
+        d = mk(in.dx[i], in.dy[i], in.dz[i]);
+        const V3 x = add(o, scale(d, t));                               // camera.cpp:68
+        V3 nrm = normalize(mk(hit.nx[i], hit.ny[i], hit.nz[i]));        // camera.cpp:69
+        if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);              // camera.cpp:72-73
+
+        PathRng rng;
+        rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
+        const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
+
+        if (PHASE == 1) {
+          sd.x[i] = x.x; sd.y[i] = x.y; sd.z[i] = x.z;
+          for (uint32_t l = 0; l < S.n_lights; ++l) {
+            V3 to, w;
+            sample_light(S, rng, base, l, x, nrm, to, w);
+            const size_t k = (size_t)l * n + i;
+            sd.tx[k] = to.x; sd.ty[k] = to.y; sd.tz[k] = to.z;
+            sd.wx[k] = w.x; sd.wy[k] = w.y; sd.wz[k] = w.z;
+          }
+        } else {
+          const uint32_t mat_id = hit.mat[i];
+          const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
+          const float4 m0 = mp[0], m1 = mp[1];
+          const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
+          // direct light: every light at every vertex, camera.cpp:96-115
+          V3 local = mk(0, 0, 0);
+          for (uint32_t l = 0; l < S.n_lights; ++l) {
+            if (PHASE == 0) {
+              V3 to, w;
+              sample_light(S, rng, base, l, x, nrm, to, w);
+              HitRec sh;
+              // camera.cpp:101-102: the light is skipped only when this ray hits nothing
+              if (!walk<MODE, true, COUNT, false, RES>(S, C, x, to, stk, BLOCK, sh, nb, nt)) continue;
+              local = add(local, w);
+            } else {
+              const size_t k = (size_t)l * n + i;
+              if (!sd.vis[k]) continue;
+              local = add(local, mk(sd.wx[k], sd.wy[k], sd.wz[k]));
+            }
+          }
+
+          // Russian roulette (camera.cpp:118-119) was drawn by k_trace_queue: `cont`
+          if (cont) local = add(local, ke);  // camera.cpp:154
+          L = add(L, mul(T, local));
+          if (cont) {
+            const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
+            const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
+            V3 w;
+            const uint32_t tex = __float_as_uint(m0.w);
+            const bool textured = TEX && tex != 0;                                // camera.cpp:121
+            V3 texel = mk(0, 0, 0);
+            if (textured) texel = texel_brdf(S, tex, hit.slot[i], hit.u[i], hit.v[i]);
+            if (F.sampling == PT_SAMPLE_COSINE) {
+              w = cosine_dir(nrm, rx, ry);
+              T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob);
+            } else {
+              w = uniform_dir(nrm, rx, ry);
+              const V3 brdf = textured ? texel : divs(kd, F.pi_f);                // camera.cpp:122-146
+              T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+            }
+            o = x;  // no offset along the normal, camera.cpp:155
+            d = w;
+            alive = true;
+          }
+        }
+      }
+    }
+    if (PHASE == 1) continue;
+    n_hit += (uint32_t)__popcll(__ballot(did_hit));
+    if (alive) {
+      const uint32_t j = block_off[(run + c) / kScanSpan] + chunk_base[run + c] +
+                         (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      out.ox[j] = o.x; out.oy[j] = o.y; out.oz[j] = o.z;
+      out.dx[j] = d.x; out.dy[j] = d.y; out.dz[j] = d.z;
+      out.tx[j] = T.x; out.ty[j] = T.y; out.tz[j] = T.z;
+      out.lx[j] = L.x; out.ly[j] = L.y; out.lz[j] = L.z;
+      out.id[j] = id;
+    } else if (active) {
+      Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
+    }
+  }
+  if (PHASE != 1 && lane == 0 && n_hit) atomicAdd(&cnt[1], n_hit);
+  if (COUNT && PHASE == 0) {
+    wave_add64(stats + 2, nb);
+    wave_add64(stats + 3, nt);
+  }
+}
+
+// Exclusive prefix sums of the survivor counts popcount(chunk_mask[c]), two levels:
+// k_scan_local scans kScanSpan chunks per workgroup and leaves each workgroup's total in
+// block_tot; k_scan_top scans those totals in place and writes the grand total to *total.
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_t &block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < (int)(blockDim.x >> 6) ? wave_tot[lane] : 0u;
+    uint32_t winc = w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(winc, off);
+      if (lane >= off) winc += t;
+    }
+    if (lane < (int)(blockDim.x >> 6)) wave_tot[lane] = winc - w;
+    if (lane == 63) wave_tot[64] = winc;
+  }
+  __syncthreads();
+  block_total = wave_tot[64];
+  return wave_tot[wave] + inc - v;
+}
+
+// 8 bytes that are each 0 or 1 -> 8 bits, byte k to bit k (the products land on distinct bits).
+__device__ __forceinline__ unsigned long long pack8(unsigned long long w) { return (w * 0x0102040810204080ull) >> 56; }
+
+// Also turns the per-ray survivor bytes of k_trace_queue into the 64-bit mask of each chunk.
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(uint32_t n, uint32_t n_chunks, const uint8_t *alive,
+                                                           unsigned long long *chunk_mask, uint32_t *chunk_base,
+                                                           uint32_t *block_tot) {
+  __shared__ uint32_t wave_tot[65];
+  const uint32_t first = (blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
+  uint32_t c[kScanPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    c[k] = 0u;
+    if (first + k < n_chunks) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(alive + (size_t)(first + k) * 64u);
+      unsigned long long m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 w = p[j];
+        m |= (pack8((unsigned long long)w.x | ((unsigned long long)w.y << 32)) |
+              (pack8((unsigned long long)w.z | ((unsigned long long)w.w << 32)) << 8)) << (16 * j);
+      }
+      const uint32_t valid = n - (first + k) * 64u;  // the last chunk may be short; its tail bytes were never written
+      if (valid < 64u) m &= (1ull << valid) - 1ull;
+      chunk_mask[first + k] = m;
+      c[k] = (uint32_t)__popcll(m);
+    }
+    sum += c[k];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(sum, wave_tot, total);
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    if (first + k < n_chunks) chunk_base[first + k] = run;
+    run += c[k];
+  }
+  if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t n_blocks, uint32_t *block_tot, uint32_t *total) {
+  __shared__ uint32_t wave_tot[65];
+  const uint32_t v = threadIdx.x < n_blocks ? block_tot[threadIdx.x] : 0u;
+  uint32_t all;
+  const uint32_t ex = block_exclusive_scan(v, wave_tot, all);
+  if (threadIdx.x < n_blocks) block_tot[threadIdx.x] = ex;
+  if (threadIdx.x == 0) *total = all;
+}
+
+// accum[p] += sum over the batch's samples, in sample order (so the float sum does not
+// depend on how paths were scheduled).
+__global__ __launch_bounds__(kBlock) void k_resolve(uint32_t P, uint32_t S, const float *Lr, const float *Lg,
+                                                    const float *Lb, float *accum) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  float r = accum[3 * (size_t)p + 0], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
+  for (uint32_t s = 0; s < S; ++s) {
+    const size_t k = (size_t)s * P + p;
+    r += Lr[k]; g += Lg[k]; b += Lb[k];
+  }
+  accum[3 * (size_t)p + 0] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
+}
+
+#endif
