@@ -52,7 +52,7 @@ struct Workspace {
   float *block = nullptr;  // 2 queues x 13 arrays + 8 hit arrays + 3 radiance arrays
   QueueDev q[2];
   HitDev hit{};
-  float *Lr = nullptr, *Lg = nullptr, *Lb = nullptr;
+  RadDev rad{};
   unsigned long long *chunk_mask = nullptr;  // one per 64 queue entries
   uint32_t *chunk_base = nullptr;
   uint32_t *block_tot = nullptr;             // one per kScanSpan chunks, at most kScanBlock
@@ -193,19 +193,19 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   if ((n_chunks + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock) return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
   const size_t extra = n_chunks * 12 + (size_t)kScanBlock * 4 + 256 + stride;
   HIP_TRY(hipMalloc(&w.block, arrays * stride * sizeof(float) + extra));
+  if (stride > 0x7fffffffu) return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
   float *p = w.block;
-  auto take = [&]() { float *r = p; p += stride; return r; };
   for (int k = 0; k < 2; ++k) {
-    QueueDev &q = w.q[k];
-    q.ox = take(); q.oy = take(); q.oz = take(); q.dx = take(); q.dy = take(); q.dz = take();
-    q.tx = take(); q.ty = take(); q.tz = take(); q.lx = take(); q.ly = take(); q.lz = take();
-    q.id = reinterpret_cast<uint32_t *>(take());
+    w.q[k].base = p;
+    w.q[k].stride = (uint32_t)stride;
+    p += 13 * stride;
   }
-  w.hit.t = take(); w.hit.nx = take(); w.hit.ny = take(); w.hit.nz = take();
-  w.hit.mat = reinterpret_cast<uint32_t *>(take());
-  w.hit.u = take(); w.hit.v = take();
-  w.hit.slot = reinterpret_cast<uint32_t *>(take());
-  w.Lr = take(); w.Lg = take(); w.Lb = take();
+  w.hit.base = p;
+  w.hit.stride = (uint32_t)stride;
+  p += 8 * stride;
+  w.rad.base = p;
+  w.rad.stride = (uint32_t)stride;
+  p += 3 * stride;
   w.chunk_mask = reinterpret_cast<unsigned long long *>(p);
   w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
   w.block_tot = w.chunk_base + n_chunks;
@@ -217,11 +217,11 @@ static int ensure_workspace(PtScene *s, size_t cap) {
       free_workspace(w);
       return fail(PT_ERR_NOMEM, "out of device memory for the visibility-ray workspace");
     }
-    float *sp = w.shadow_block;
-    w.sd.x = sp; sp += stride; w.sd.y = sp; sp += stride; w.sd.z = sp; sp += stride;
-    w.sd.tx = sp; sp += items; w.sd.ty = sp; sp += items; w.sd.tz = sp; sp += items;
-    w.sd.wx = sp; sp += items; w.sd.wy = sp; sp += items; w.sd.wz = sp; sp += items;
-    w.sd.vis = reinterpret_cast<uint8_t *>(sp);
+    w.sd.vbase = w.shadow_block;
+    w.sd.vstride = (uint32_t)stride;
+    w.sd.ibase = w.shadow_block + 3 * stride;
+    w.sd.istride = items;
+    w.sd.vis_ = reinterpret_cast<uint8_t *>(w.sd.ibase + 6 * items);
     w.shadow_items = items;
   }
   w.cap = cap;
@@ -265,7 +265,7 @@ static int dispatch_plan(const Plan &p, F &&f) {
 }
 
 template <int MODE, bool COUNT>
-static int launch_trace_queue(PtScene *s, const FrameDev &F, int depth, uint32_t n, const QueueDev &q, hipStream_t st) {
+static int launch_trace_queue(PtScene *s, const PathFrame &F, int depth, uint32_t n, const QueueDev &q, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
     auto k = !s->plan.resident ? k_trace_queue<MODE, BLOCK, COUNT, false, true>
@@ -280,7 +280,7 @@ static int launch_trace_queue(PtScene *s, const FrameDev &F, int depth, uint32_t
 }
 
 template <int MODE, bool COUNT>
-static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, const QueueDev &in,
+static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, const QueueDev &in,
                         const QueueDev &out, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
@@ -293,7 +293,7 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
       int rc = allow_lds(k, s->plan.lds_bytes);
       if (rc != PT_OK) return rc;
       hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, kRun, F, depth, n, in,
-                         w.hit, out, w.sd, w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+                         w.hit, out, w.sd, w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.rad, s->d_stats);
       HIP_TRY(hipGetLastError());
       return PT_OK;
     }
@@ -301,7 +301,7 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
     if ((size_t)n * s->dev.n_lights > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
     auto ka = k_shade<MODE, BLOCK, COUNT, false, 1, false>;
     hipLaunchKernelGGL(ka, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
-                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.rad, s->d_stats);
     HIP_TRY(hipGetLastError());
     auto kw = s->plan.resident ? k_shadow_walk<MODE, BLOCK, COUNT, true> : k_shadow_walk<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(kw, s->plan.lds_bytes);
@@ -312,7 +312,7 @@ static int launch_shade(PtScene *s, const FrameDev &F, int depth, uint32_t n, co
     HIP_TRY(hipGetLastError());
     auto kb = s->dev.n_tex != 0 ? k_shade<MODE, BLOCK, COUNT, false, 2, true> : k_shade<MODE, BLOCK, COUNT, false, 2, false>;
     hipLaunchKernelGGL(kb, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
-                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.Lr, w.Lg, w.Lb, s->d_stats);
+                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.rad, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -365,6 +365,15 @@ static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *o
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
+}
+
+static PathFrame path_frame(const FrameDev &F) {
+  PathFrame p;
+  p.P = F.P; p.seed = F.seed; p.sample0 = F.sample0; p.stride = F.stride;
+  p.rr_prob = F.rr_prob; p.rr_min_depth = F.rr_min_depth; p.max_depth = F.max_depth; p.sampling = F.sampling;
+  for (int k = 0; k < 3; ++k) p.bg[k] = F.bg[k];
+  p.pdf_f = F.pdf_f; p.pi_f = F.pi_f; p.dims_per_vertex = F.dims_per_vertex;
+  return p;
 }
 
 static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const PtOptions *opt, uint32_t n_lights,
@@ -785,6 +794,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     const uint32_t sb = (spp_count - done) < batch ? (spp_count - done) : batch;
     uint32_t n = sb * F.P;
     F.sample0 = spp_begin + done * F.stride;
+    const PathFrame PF = path_frame(F);
     if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
     hipLaunchKernelGGL(k_raygen, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F, n, w.q[0]);
     HIP_TRY(hipGetLastError());
@@ -799,16 +809,16 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
       HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
       if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
-      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], st);
-      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], st);
+      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, PF, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, PF, depth, n, w.q[cur], st);
+      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, PF, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, PF, depth, n, w.q[cur], st);
       if (rc != PT_OK) return rc;
       const uint32_t n_chunks = (n + 63) / 64, n_sblocks = (n_chunks + kScanSpan - 1) / kScanSpan;
       hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n, n_chunks, w.alive, w.chunk_mask, w.chunk_base, w.block_tot);
       hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, s->d_cnt);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
-      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_EXACT, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st);
-      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_FAST, false>(s, F, depth, n, w.q[cur], w.q[cur ^ 1], st);
+      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_EXACT, false>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st);
+      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_FAST, false>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st);
       if (rc != PT_OK) return rc;
       if (prof) HIP_TRY(hipEventRecord(s->ev[2], st));
       HIP_TRY(hipMemcpyAsync(s->h_cnt, s->d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -826,7 +836,7 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
       n = s->h_cnt[0];
     }
     if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
-    hipLaunchKernelGGL(k_resolve, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, w.Lr, w.Lg, w.Lb, accum);
+    hipLaunchKernelGGL(k_resolve, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, w.rad, accum);
     HIP_TRY(hipGetLastError());
     if (prof) {
       HIP_TRY(hipEventRecord(s->ev[3], st));

@@ -20,19 +20,62 @@ static const int kScanBlock = 1024;
 static const int kScanPer = 4;
 static const int kScanSpan = kScanBlock * kScanPer;  // chunks one workgroup of k_scan_local covers
 
-struct QueueDev {  // one live path per index, arrays `cap` long
-  float *ox, *oy, *oz, *dx, *dy, *dz;  // ray
-  float *tx, *ty, *tz;                 // throughput
-  float *lx, *ly, *lz;                 // radiance gathered so far
-  uint32_t *id;                        // sample_in_batch * P + pixel
+// Structure-of-arrays buffers are handed to the kernels as one base pointer and the distance
+// between consecutive arrays: a kernel argument list of some fifty separate pointers did not fit
+// the scalar registers and the shading kernel spent 13 % of its vector instructions spilling
+// them into vector lanes.
+
+struct QueueDev {  // one live path per index; 13 arrays `stride` floats apart
+  float *base;
+  uint32_t stride;
+  __device__ __forceinline__ float *arr(uint32_t k) const { return base + (size_t)k * stride; }
+  __device__ __forceinline__ float *ox() const { return arr(0); }  // ray
+  __device__ __forceinline__ float *oy() const { return arr(1); }
+  __device__ __forceinline__ float *oz() const { return arr(2); }
+  __device__ __forceinline__ float *dx() const { return arr(3); }
+  __device__ __forceinline__ float *dy() const { return arr(4); }
+  __device__ __forceinline__ float *dz() const { return arr(5); }
+  __device__ __forceinline__ float *tx() const { return arr(6); }  // throughput
+  __device__ __forceinline__ float *ty() const { return arr(7); }
+  __device__ __forceinline__ float *tz() const { return arr(8); }
+  __device__ __forceinline__ float *lx() const { return arr(9); }  // radiance gathered so far
+  __device__ __forceinline__ float *ly() const { return arr(10); }
+  __device__ __forceinline__ float *lz() const { return arr(11); }
+  __device__ __forceinline__ uint32_t *id() const { return reinterpret_cast<uint32_t *>(arr(12)); }  // sample_in_batch * P + pixel
 };
 
-struct HitDev {  // closest hit of every queued ray
-  float *t;
-  float *nx, *ny, *nz;  // Triangle::normal() of the hit triangle, un-normalised
-  uint32_t *mat;
-  float *u, *v;         // barycentrics and triangle record of the hit: written and read only when
-  uint32_t *slot;       // the scene has a textured material
+struct HitDev {  // closest hit of every queued ray; 8 arrays `stride` floats apart
+  float *base;
+  uint32_t stride;
+  __device__ __forceinline__ float *arr(uint32_t k) const { return base + (size_t)k * stride; }
+  __device__ __forceinline__ float *t() const { return arr(0); }
+  __device__ __forceinline__ float *nx() const { return arr(1); }  // Triangle::normal() of the hit triangle, un-normalised
+  __device__ __forceinline__ float *ny() const { return arr(2); }
+  __device__ __forceinline__ float *nz() const { return arr(3); }
+  __device__ __forceinline__ uint32_t *mat() const { return reinterpret_cast<uint32_t *>(arr(4)); }
+  __device__ __forceinline__ float *u() const { return arr(5); }   // barycentrics and triangle record of the hit:
+  __device__ __forceinline__ float *v() const { return arr(6); }   // written and read only when the scene has a
+  __device__ __forceinline__ uint32_t *slot() const { return reinterpret_cast<uint32_t *>(arr(7)); }  // textured material
+};
+
+struct RadDev {  // finished radiance per (sample in batch, pixel): r, g, b arrays `stride` floats apart
+  float *base;
+  uint32_t stride;
+  __device__ __forceinline__ float *ch(uint32_t k) const { return base + (size_t)k * stride; }
+};
+
+// What the per-path kernels need of a frame (the camera part stays in FrameDev for k_raygen).
+struct PathFrame {
+  uint32_t P;            // W*H
+  uint64_t seed;
+  uint32_t sample0;      // global index of the batch's first sample
+  uint32_t stride;       // distance between consecutive samples' global indices
+  float rr_prob;
+  int rr_min_depth, max_depth, sampling;
+  float bg[3];
+  float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
+  float pi_f;            // (float)M_PI, camera.cpp:122
+  uint32_t dims_per_vertex;
 };
 
 struct FrameDev {
@@ -103,11 +146,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameDev F, uint32_t n, Queue
   rng.init(F.seed, p, F.sample0 + s * F.stride);
   V3 o, d;
   camera_ray(F, px, py, rng, o, d);
-  q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
-  q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
-  q.tx[i] = 1.0f; q.ty[i] = 1.0f; q.tz[i] = 1.0f;
-  q.lx[i] = 0.0f; q.ly[i] = 0.0f; q.lz[i] = 0.0f;
-  q.id[i] = i;
+  q.ox()[i] = o.x; q.oy()[i] = o.y; q.oz()[i] = o.z;
+  q.dx()[i] = d.x; q.dy()[i] = d.y; q.dz()[i] = d.z;
+  q.tx()[i] = 1.0f; q.ty()[i] = 1.0f; q.tz()[i] = 1.0f;
+  q.lx()[i] = 0.0f; q.ly()[i] = 0.0f; q.lz()[i] = 0.0f;
+  q.id()[i] = i;
 }
 
 // Camera::point_towards for every pixel, for callers that only want the directions.
@@ -265,12 +308,12 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
 
 // Does the path of queue entry i go on after a vertex whose closest hit is at t?  It does iff it
 // hit something and passes Russian roulette (camera.cpp:65, 118-119).
-__device__ __forceinline__ bool survives(const SceneDev &S, const FrameDev &F, int depth, const QueueDev &q, uint32_t i,
+__device__ __forceinline__ bool survives(const SceneDev &S, const PathFrame &F, int depth, const QueueDev &q, uint32_t i,
                                          float t) {
   if (t == __builtin_inff()) return false;
   if (F.max_depth > 0 && depth >= F.max_depth) return false;
   if (depth <= F.rr_min_depth) return true;  // the roulette draw exists only when depth > rr_min_depth
-  const uint32_t id = q.id[i];
+  const uint32_t id = q.id()[i];
   PathRng rng;
   rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
   const uint32_t dim = 2u + (uint32_t)depth * F.dims_per_vertex + 3u * S.n_lights;
@@ -282,7 +325,7 @@ __device__ __forceinline__ bool survives(const SceneDev &S, const FrameDev &F, i
 // 64-bit mask of each chunk, so that the survivors' places in the next queue are known before
 // the shading kernel writes them.
 template <int MODE, int BLOCK, bool COUNT, bool RES, bool REFILL>
-__global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth,
+__global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, PathFrame F, int depth,
                                                        uint32_t n, QueueDev q, HitDev hit, uint8_t *alive_out,
                                                        uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
@@ -291,18 +334,18 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
   walk_items<MODE, false, COUNT, true, RES, REFILL, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
-        o = mk(q.ox[i], q.oy[i], q.oz[i]);
-        d = mk(q.dx[i], q.dy[i], q.dz[i]);
+        o = mk(q.ox()[i], q.oy()[i], q.oz()[i]);
+        d = mk(q.dx()[i], q.dy()[i], q.dz()[i]);
         return true;
       },
       [&](uint64_t i, const RayState &st) {
         const HitRec &h = st.best;
-        hit.t[i] = h.t;
-        hit.nx[i] = h.n.x; hit.ny[i] = h.n.y; hit.nz[i] = h.n.z;
-        hit.mat[i] = h.mat;
+        hit.t()[i] = h.t;
+        hit.nx()[i] = h.n.x; hit.ny()[i] = h.n.y; hit.nz()[i] = h.n.z;
+        hit.mat()[i] = h.mat;
         if (S.n_tex) {
-          hit.u[i] = h.u; hit.v[i] = h.v;
-          hit.slot[i] = h.slot;
+          hit.u()[i] = h.u; hit.v()[i] = h.v;
+          hit.slot()[i] = h.slot;
         }
         alive_out[i] = survives(S, F, depth, q, (uint32_t)i, h.t) ? 1 : 0;
       });
@@ -419,10 +462,21 @@ __global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, ui
 // Visibility rays of the split shading pipeline (scenes outside LDS): item k = l*n + i is the
 // ray from vertex i towards its sample of light l, prepared by k_shade<..., 1>.
 struct ShadowDev {
-  float *x, *y, *z;        // per vertex: hit point
-  float *tx, *ty, *tz;     // per item: direction towards the light sample
-  float *wx, *wy, *wz;     // per item: what the light adds if the ray hits anything (camera.cpp:101-114)
-  uint8_t *vis;            // per item: the ray hit something
+  float *vbase;            // per vertex: hit point x, y, z; arrays vstride floats apart
+  uint32_t vstride;
+  float *ibase;            // per item: direction towards the light sample (3 arrays), then what the light adds if
+  size_t istride;          // the ray hits anything (camera.cpp:101-114; 3 arrays); arrays istride floats apart
+  uint8_t *vis_;           // per item: the ray hit something
+  __device__ __forceinline__ float *x() const { return vbase; }
+  __device__ __forceinline__ float *y() const { return vbase + vstride; }
+  __device__ __forceinline__ float *z() const { return vbase + 2 * (size_t)vstride; }
+  __device__ __forceinline__ float *tx() const { return ibase; }
+  __device__ __forceinline__ float *ty() const { return ibase + istride; }
+  __device__ __forceinline__ float *tz() const { return ibase + 2 * istride; }
+  __device__ __forceinline__ float *wx() const { return ibase + 3 * istride; }
+  __device__ __forceinline__ float *wy() const { return ibase + 4 * istride; }
+  __device__ __forceinline__ float *wz() const { return ibase + 5 * istride; }
+  __device__ __forceinline__ uint8_t *vis() const { return vis_; }
 };
 
 template <int MODE, int BLOCK, bool COUNT, bool RES>
@@ -435,12 +489,12 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_walk(SceneDev S, LdsPlan plan,
       S, C, stk, (uint64_t)n * S.n_lights, kRun, head, nb, nt,
       [&](uint64_t k, V3 &o, V3 &d) {
         const uint32_t i = (uint32_t)(k % n);
-        if (hit.t[i] == __builtin_inff()) return false;  // no vertex, no light loop: nobody reads vis[k]
-        o = mk(sd.x[i], sd.y[i], sd.z[i]);
-        d = mk(sd.tx[k], sd.ty[k], sd.tz[k]);
+        if (hit.t()[i] == __builtin_inff()) return false;  // no vertex, no light loop: nobody reads vis[k]
+        o = mk(sd.x()[i], sd.y()[i], sd.z()[i]);
+        d = mk(sd.tx()[k], sd.ty()[k], sd.tz()[k]);
         return true;
       },
-      [&](uint64_t k, const RayState &st) { sd.vis[k] = st.found ? 1 : 0; });
+      [&](uint64_t k, const RayState &st) { sd.vis()[k] = st.found ? 1 : 0; });
   if (COUNT) {
     wave_add64(stats + 2, nb);
     wave_add64(stats + 3, nt);
@@ -544,11 +598,11 @@ __device__ __forceinline__ void sample_light(const SceneDev &S, PathRng &rng, ui
 // with the answers.  The weights w are added in light order in both forms, so the sums agree
 // bit for bit.  TEX: the scene has a diffuse map (untextured scenes run without that code).
 template <int MODE, int BLOCK, bool COUNT, bool RES, int PHASE, bool TEX>
-__global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, FrameDev F, int depth, uint32_t n,
+__global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint32_t kRun, PathFrame F, int depth, uint32_t n,
                                                  QueueDev in, HitDev hit, QueueDev out, ShadowDev sd,
                                                  const unsigned long long *chunk_mask, const uint32_t *chunk_base,
-                                                 const uint32_t *block_off, uint32_t *cnt, float *Lr, float *Lg,
-                                                 float *Lb, unsigned long long *stats) {
+                                                 const uint32_t *block_off, uint32_t *cnt, RadDev rad,
+                                                 unsigned long long *stats) {
   uint32_t stk = 0;
   LdsScene C{};
   if constexpr (PHASE == 0) C = stage_scene<BLOCK>(S, plan, stk);
@@ -570,20 +624,20 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
     uint32_t id = 0;
     if (active) {
-      id = in.id[i];
-      const float t = hit.t[i];
+      id = in.id()[i];
+      const float t = hit.t()[i];
       if (PHASE != 1) {
-        T = mk(in.tx[i], in.ty[i], in.tz[i]);
-        L = mk(in.lx[i], in.ly[i], in.lz[i]);
+        T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
+        L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
       }
       if (t == __builtin_inff()) {  // camera.cpp:65-66
         L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
       } else {
         did_hit = true;
-        o = mk(in.ox[i], in.oy[i], in.oz[i]);
-        d = mk(in.dx[i], in.dy[i], in.dz[i]);
+        o = mk(in.ox()[i], in.oy()[i], in.oz()[i]);
+        d = mk(in.dx()[i], in.dy()[i], in.dz()[i]);
         const V3 x = add(o, scale(d, t));                               // camera.cpp:68
-        V3 nrm = normalize(mk(hit.nx[i], hit.ny[i], hit.nz[i]));        // camera.cpp:69
+        V3 nrm = normalize(mk(hit.nx()[i], hit.ny()[i], hit.nz()[i]));        // camera.cpp:69
         if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);              // camera.cpp:72-73
 
         PathRng rng;
@@ -591,16 +645,16 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
         const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
 
         if (PHASE == 1) {
-          sd.x[i] = x.x; sd.y[i] = x.y; sd.z[i] = x.z;
+          sd.x()[i] = x.x; sd.y()[i] = x.y; sd.z()[i] = x.z;
           for (uint32_t l = 0; l < S.n_lights; ++l) {
             V3 to, w;
             sample_light(S, rng, base, l, x, nrm, to, w);
             const size_t k = (size_t)l * n + i;
-            sd.tx[k] = to.x; sd.ty[k] = to.y; sd.tz[k] = to.z;
-            sd.wx[k] = w.x; sd.wy[k] = w.y; sd.wz[k] = w.z;
+            sd.tx()[k] = to.x; sd.ty()[k] = to.y; sd.tz()[k] = to.z;
+            sd.wx()[k] = w.x; sd.wy()[k] = w.y; sd.wz()[k] = w.z;
           }
         } else {
-          const uint32_t mat_id = hit.mat[i];
+          const uint32_t mat_id = hit.mat()[i];
           const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
           const float4 m0 = mp[0], m1 = mp[1];
           const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
@@ -616,8 +670,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
               local = add(local, w);
             } else {
               const size_t k = (size_t)l * n + i;
-              if (!sd.vis[k]) continue;
-              local = add(local, mk(sd.wx[k], sd.wy[k], sd.wz[k]));
+              if (!sd.vis()[k]) continue;
+              local = add(local, mk(sd.wx()[k], sd.wy()[k], sd.wz()[k]));
             }
           }
 
@@ -631,7 +685,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
             const uint32_t tex = __float_as_uint(m0.w);
             const bool textured = TEX && tex != 0;                                // camera.cpp:121
             V3 texel = mk(0, 0, 0);
-            if (textured) texel = texel_brdf(S, tex, hit.slot[i], hit.u[i], hit.v[i]);
+            if (textured) texel = texel_brdf(S, tex, hit.slot()[i], hit.u()[i], hit.v()[i]);
             if (F.sampling == PT_SAMPLE_COSINE) {
               w = cosine_dir(nrm, rx, ry);
               T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob);
@@ -652,13 +706,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
     if (alive) {
       const uint32_t j = block_off[(run + c) / kScanSpan] + chunk_base[run + c] +
                          (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      out.ox[j] = o.x; out.oy[j] = o.y; out.oz[j] = o.z;
-      out.dx[j] = d.x; out.dy[j] = d.y; out.dz[j] = d.z;
-      out.tx[j] = T.x; out.ty[j] = T.y; out.tz[j] = T.z;
-      out.lx[j] = L.x; out.ly[j] = L.y; out.lz[j] = L.z;
-      out.id[j] = id;
+      out.ox()[j] = o.x; out.oy()[j] = o.y; out.oz()[j] = o.z;
+      out.dx()[j] = d.x; out.dy()[j] = d.y; out.dz()[j] = d.z;
+      out.tx()[j] = T.x; out.ty()[j] = T.y; out.tz()[j] = T.z;
+      out.lx()[j] = L.x; out.ly()[j] = L.y; out.lz()[j] = L.z;
+      out.id()[j] = id;
     } else if (active) {
-      Lr[id] = L.x; Lg[id] = L.y; Lb[id] = L.z;
+      rad.ch(0)[id] = L.x; rad.ch(1)[id] = L.y; rad.ch(2)[id] = L.z;
     }
   }
   if (PHASE != 1 && lane == 0 && n_hit) atomicAdd(&cnt[1], n_hit);
@@ -748,8 +802,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t n_blocks, uint
 
 // accum[p] += sum over the batch's samples, in sample order (so the float sum does not
 // depend on how paths were scheduled).
-__global__ __launch_bounds__(kBlock) void k_resolve(uint32_t P, uint32_t S, const float *Lr, const float *Lg,
-                                                    const float *Lb, float *accum) {
+__global__ __launch_bounds__(kBlock) void k_resolve(uint32_t P, uint32_t S, RadDev rad, float *accum) {
+  const float *Lr = rad.ch(0), *Lg = rad.ch(1), *Lb = rad.ch(2);
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= P) return;
   float r = accum[3 * (size_t)p + 0], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
