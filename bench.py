@@ -87,9 +87,9 @@ def cpu_baseline(meshes, mats, cfg, cam_kw, opt_kw):
 # Named settings of the larger configurations: the 260 k-triangle one is quoted with 5 bounces and
 # depth of field on.  `spp` here is the short sample count of the secondary report lines.
 OTHERS = {
-    "atrium260k": dict(spp=16, max_depth=5, aperture=0.05),
-    "blob7m": dict(spp=4),
-    "terrain1m": dict(spp=1),
+    "atrium260k": dict(spp=32, max_depth=5, aperture=0.05),
+    "blob7m": dict(spp=16),
+    "terrain1m": dict(spp=2),
 }
 
 
