@@ -95,6 +95,14 @@ def lib():
     """Loads libptgpu.so (raises OSError when it has not been built)."""
     global _lib
     if _lib is None:
+        # PyTorch wheels carry a HIP runtime of their own.  If this library (linked against the
+        # system's) initialises the GPU first and torch is imported afterwards, torch finds no
+        # device; with torch loaded first both share one runtime.  So when torch is installed it
+        # is imported here, before the library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.pt_last_error.restype = C.c_char_p
         L.pt_device_count.restype = C.c_int

@@ -169,3 +169,32 @@ def test_headless_driver_renders_plane_obj(tmp_path):
     lines = open(out).read().split("\n")
     assert lines[:3] == ["P3", "256 256", "255"]    # the reference's fixed size and spp (main.cpp:41-42)
     assert set(lines[3:3 + 256 * 256]) == {"0 0 0"}  # no emitter, black background
+
+
+def test_host_pointer_calls_cross_their_staging_chunk():
+    """pt_trace_closest / pt_trace_any / pt_trace_hits stage host rays through the device 2^24 at a
+    time: the answers on either side of that boundary must be those of the same rays sent alone."""
+    from pathtracer_amd import api
+    from tests import util
+    w = util.world("box")
+    ds = api.DeviceScene(w.export())
+    n = (1 << 24) + 777
+    base_o, base_d = util.random_rays(4096, 5)
+    reps = -(-n // 4096)
+    o = np.tile(base_o, (reps, 1))[:n]
+    d = np.tile(base_d, (reps, 1))[:n]
+    small = ds.trace_closest(base_o, base_d)
+    small_any = np.asarray(ds.trace_any(base_o, base_d))
+    small_hits = ds.trace_hits(base_o, base_d)
+    big = ds.trace_closest(o, d)
+    big_any = np.asarray(ds.trace_any(o, d))
+    big_hits = ds.trace_hits(o, d)
+    ds.close()
+    idx = np.arange(n) % 4096
+    for lo, hi in ((0, 5000), ((1 << 24) - 3000, n)):
+        s = slice(lo, hi)
+        assert (big["tri"][s] == small["tri"][idx[s]]).all()
+        assert (big["t"][s].view(np.uint32) == small["t"][idx[s]].view(np.uint32)).all()
+        assert (big_any[s] == small_any[idx[s]]).all()
+        assert (big_hits[s] == small_hits[idx[s]]).all()
+    assert (big["tri"] == small["tri"][idx]).all()
