@@ -231,7 +231,16 @@ static int ensure_workspace(PtScene *s, size_t cap) {
 // Dynamic LDS above 64 KiB has to be allowed per kernel once.
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  // once per kernel, device and size: the call costs microseconds and a frame has hundreds of launches
+  static thread_local std::vector<std::pair<const void *, unsigned long long>> done;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  const unsigned long long key = ((unsigned long long)dev << 32) | (unsigned long long)bytes;
+  for (const auto &e : done)
+    if (e.first == fn && e.second == key) return PT_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done.emplace_back(fn, key);
   return PT_OK;
 }
 
