@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+VALU_PEAK_GINST = 1024 * 2.4 / 4  # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, 4 cycles each, 2.4 GHz
 
 
 def parse():
@@ -183,11 +184,14 @@ def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank,
         bytes_step = 32.0 * nb + 36.0 * nt + 48.0 * nr
         launches = max(1, int(prof["trace_launches"]))
         gbs = bytes_step * K / (prof["trace_ms"] * 1e-3) / 1e9 if prof["trace_ms"] > 0 else 0.0
-        traffic = None
+        traffic = valu_insts = lanes = None
         pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % name)
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("trace_closest_hbm_bytes_per_launch")
+                rec = json.load(f)
+            traffic = rec.get("trace_closest_hbm_bytes_per_launch")
+            valu_insts = rec.get("trace_closest_valu_insts_per_launch")
+            lanes = rec.get("trace_closest_active_lanes")
         scene_bytes = 64.0 * ds.info["n_wide_nodes"] + 48.0 * ds.info["n_tris"]
         res["roofline"] = {
             "bound": "hbm", "kernel": "k_trace_queue (closest hit)",
@@ -205,6 +209,13 @@ def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank,
             "scene_lds_resident": bool(scene_bytes <= 150 * 1024),
             "queue_bytes_gbs": 44.0 * nr * K / (prof["trace_ms"] * 1e-3) / 1e9 if prof["trace_ms"] > 0 else 0.0,
         }
+        if valu_insts and prof["trace_ms"] > 0:
+            # what does bound an LDS-resident scene: wave-level vector instructions per second against
+            # the issue peak of 1024 SIMDs at one wave64 instruction per 4 cycles of 2.4 GHz; counts
+            # per launch from the rocprofv3 counter pass kept under profiles/, time measured here
+            rate = valu_insts / (prof["trace_ms"] * 1e-3 / launches)
+            res["roofline"]["valu_issue"] = {"achieved": rate / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                                            "frac": rate / 1e9 / VALU_PEAK_GINST, "active_lanes_of_64": lanes}
     ds.close()
     scene.close()
     return res, (meshes, mats, cam_kw, {k: v for k, v in opt_kw.items() if k not in ("trace_mode", "batch_spp")})
