@@ -122,9 +122,11 @@ enum { PT_TRACE_EXACT = 0, PT_TRACE_FAST = 1 };
 /* Integrator constants.  pt_options_default() fills in the reference literals
  * (camera.cpp:52,118-119,152). */
 typedef struct PtOptions {
-  float rr_prob;        /* 0.7 */
+  double rr_prob;       /* .7 as a double, as camera.cpp:118 declares it: the float draw is compared with it in
+                           double (camera.cpp:119), so a draw equal to 0.7f still continues */
   int32_t rr_min_depth; /* roulette only when depth > rr_min_depth; 2 */
-  int32_t max_depth;    /* 0 = unbounded (reference); k>0: a path has at most k vertices */
+  int32_t max_depth;    /* 0 = unbounded (reference); k>0: at most k bounces, i.e. the vertices at depth 0..k
+                           are traced and lit (k+1 closest-hit passes) and the path ends at depth k */
   int32_t sampling;     /* PT_SAMPLE_UNIFORM (reference) or PT_SAMPLE_COSINE (extension) */
   float bgcolor[3];     /* 0,0,0 */
   int32_t trace_mode;   /* PT_TRACE_FAST (default) or PT_TRACE_EXACT */
@@ -251,6 +253,10 @@ int pt_resolve(const float *accum_rgb_sum, size_t n, uint32_t spp, float *pixels
 /* The counter-based generator, exposed so that tests can pin it:
  * Philox-4x32-10 with counter (c0,c1,c2,c3) and key (k0,k1). */
 void pt_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* The roulette test of camera.cpp:118-119 for one draw, by the function the kernels use:
+ * 1 when a path whose draw is `draw` goes on (the float draw is compared with the double rr_prob in double). */
+int pt_roulette_pass(double rr_prob, float draw);
 
 #ifdef __cplusplus
 }

@@ -720,9 +720,12 @@ static inline Vertex shade_setup(const World &w, const Hit &h, V3 o, V3 d) {
   if (v.textured) v.texel = texel_brdf(w, m, h);
   return v;
 }
+// camera.cpp:118-119: `randreal(0, 1) < rr_prob` with `constexpr double rr_prob = .7`: the float draw is widened and
+// compared with the double, so a draw equal to 0.7f (just below .7) continues.
+static inline bool roulette_pass(double rr_prob, float draw) { return (double)draw < rr_prob; }
 static inline bool keep_going(const Frame &f, int depth, Rng &rng, uint32_t base) {
   uint32_t L = (uint32_t)f.w->lights.size();
-  bool cont = depth <= f.opt.rr_min_depth || (double)rng.real(0, 1, base + 3 * L) < (double)f.opt.rr_prob;
+  bool cont = depth <= f.opt.rr_min_depth || roulette_pass(f.opt.rr_prob, rng.real(0, 1, base + 3 * L));
   if (f.opt.max_depth > 0 && depth >= f.opt.max_depth) cont = false;
   return cont;
 }
@@ -733,7 +736,7 @@ static inline V3 next_dir(const Frame &f, V3 n, Rng &rng, uint32_t base) {
   return f.opt.sampling == PT_SAMPLE_COSINE ? cosine_dir(n, x, y) : uniform_dir(n, x, y);
 }
 // Divisor of the bounce weight: camera.cpp:152 narrowed by operator/(vec, scalar).
-static inline float pdf_f(const Frame &f) { return (float)(1 / (2 * M_PI) * (double)f.opt.rr_prob); }
+static inline float pdf_f(const Frame &f) { return (float)(1 / (2 * M_PI) * f.opt.rr_prob); }
 
 // Camera::pathtrace as written, camera.cpp:63-159.
 static V3 trace_recursive(const Frame &f, V3 o, V3 d, int depth, Rng &rng) {
@@ -748,7 +751,7 @@ static V3 trace_recursive(const Frame &f, V3 o, V3 d, int depth, Rng &rng) {
     color = add(color, v.mat->ke);
     V3 child = trace_recursive(f, v.x, w, depth + 1, rng);
     if (f.opt.sampling == PT_SAMPLE_COSINE) {
-      color = add(color, divs(mul(child, v.textured ? scale(v.texel, (float)M_PI) : v.mat->kd), f.opt.rr_prob));
+      color = add(color, divs(mul(child, v.textured ? scale(v.texel, (float)M_PI) : v.mat->kd), (float)f.opt.rr_prob));
     } else {
       V3 brdf = v.textured ? v.texel : divs(v.mat->kd, (float)M_PI);  // camera.cpp:121-146
       color = add(color, divs(scale(mul(child, brdf), std::abs(dot(v.n, w))), pdf_f(f)));
@@ -777,7 +780,7 @@ static V3 trace_iterative(const Frame &f, V3 o, V3 d, Rng &rng) {
     if (!cont) break;
     V3 w = next_dir(f, v.n, rng, base);
     if (f.opt.sampling == PT_SAMPLE_COSINE) {
-      T = divs(mul(T, v.textured ? scale(v.texel, (float)M_PI) : v.mat->kd), f.opt.rr_prob);
+      T = divs(mul(T, v.textured ? scale(v.texel, (float)M_PI) : v.mat->kd), (float)f.opt.rr_prob);
     } else {
       V3 brdf = v.textured ? v.texel : divs(v.mat->kd, (float)M_PI);
       T = divs(scale(mul(T, brdf), std::abs(dot(v.n, w))), pdf_f(f));
@@ -1064,6 +1067,8 @@ int orc_save_ppm(const char *path, const float *pixels, int32_t W, int32_t H) {
     }
   return 0;
 }
+
+int orc_roulette_pass(double rr_prob, float draw) { return roulette_pass(rr_prob, draw) ? 1 : 0; }
 
 int orc_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 

@@ -28,7 +28,7 @@ class PtCamera(C.Structure):
 
 
 class PtOptions(C.Structure):
-    _fields_ = [("rr_prob", C.c_float), ("rr_min_depth", C.c_int32), ("max_depth", C.c_int32),
+    _fields_ = [("rr_prob", C.c_double), ("rr_min_depth", C.c_int32), ("max_depth", C.c_int32),
                 ("sampling", C.c_int32), ("bgcolor", C.c_float * 3), ("trace_mode", C.c_int32),
                 ("spp_stride", C.c_uint32), ("batch_spp", C.c_uint32)]
 
@@ -107,6 +107,8 @@ def lib():
                                  C.POINTER(OrcRenderArgs), C.c_void_p, C.POINTER(PtCounters)]
         L.orc_save_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.orc_hardware_threads.restype = C.c_int
+        L.orc_roulette_pass.restype = C.c_int
+        L.orc_roulette_pass.argtypes = [C.c_double, C.c_float]
         _lib = L
     return _lib
 
@@ -246,6 +248,11 @@ def philox(ctr, key):
 def save_ppm(path, pixels):
     p = np.ascontiguousarray(pixels, np.float32)
     return lib().orc_save_ppm(os.fsencode(path), _p(p), p.shape[1], p.shape[0])
+
+
+def roulette_pass(rr_prob, draw):
+    """The roulette test of camera.cpp:118-119 for one float draw."""
+    return bool(lib().orc_roulette_pass(rr_prob, draw))
 
 
 def hardware_threads():

@@ -50,7 +50,7 @@ class PtCamera(C.Structure):
 
 
 class PtOptions(C.Structure):
-    _fields_ = [("rr_prob", C.c_float), ("rr_min_depth", C.c_int32), ("max_depth", C.c_int32),
+    _fields_ = [("rr_prob", C.c_double), ("rr_min_depth", C.c_int32), ("max_depth", C.c_int32),
                 ("sampling", C.c_int32), ("bgcolor", C.c_float * 3), ("trace_mode", C.c_int32),
                 ("spp_stride", C.c_uint32), ("batch_spp", C.c_uint32)]
 
@@ -78,7 +78,7 @@ EXPORTS = [
     "pt_scene_free", "pt_scene_info", "pt_scene_count_stats", "pt_scene_read_stats", "pt_scene_profile",
     "pt_scene_read_profile", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_trace_any", "pt_trace_hits", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
-    "pt_philox4x32",
+    "pt_philox4x32", "pt_roulette_pass",
 ]
 
 
@@ -127,6 +127,7 @@ def lib():
         L.pt_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         L.pt_philox4x32.argtypes = [C.c_void_p] * 3
         L.pt_philox4x32.restype = None
+        L.pt_roulette_pass.argtypes = [C.c_double, C.c_float]
         _lib = L
     return _lib
 

@@ -88,6 +88,10 @@ struct PathRng {
   }
 };
 
+// Russian roulette, camera.cpp:118-119: `randreal(0, 1) < rr_prob` with `constexpr double rr_prob = .7`.
+// The float draw is widened and compared with the double, so a draw equal to 0.7f (just below .7) continues.
+__host__ __device__ __forceinline__ bool roulette_pass(double rr_prob, float draw) { return (double)draw < rr_prob; }
+
 // ------------------------------------------------------------------ tree walk
 struct SceneDev {
   const ptl::WideNode *nodes;

@@ -379,7 +379,7 @@ static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *o
 static PathFrame path_frame(const FrameDev &F) {
   PathFrame p;
   p.P = F.P; p.seed = F.seed; p.sample0 = F.sample0; p.stride = F.stride;
-  p.rr_prob = F.rr_prob; p.rr_min_depth = F.rr_min_depth; p.max_depth = F.max_depth; p.sampling = F.sampling;
+  p.rr_prob = F.rr_prob; p.rr_prob_f = F.rr_prob_f; p.rr_min_depth = F.rr_min_depth; p.max_depth = F.max_depth; p.sampling = F.sampling;
   for (int k = 0; k < 3; ++k) p.bg[k] = F.bg[k];
   p.pdf_f = F.pdf_f; p.pi_f = F.pi_f; p.dims_per_vertex = F.dims_per_vertex;
   return p;
@@ -393,7 +393,7 @@ static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const Pt
   if (cam->aperture > 0 && !(cam->focus > 0)) return fail(PT_ERR_INVALID, "focus must be > 0 when aperture > 0");
   PtOptions o;
   if (opt) o = *opt; else pt_options_default(&o);
-  if (!(o.rr_prob > 0.0f)) return fail(PT_ERR_INVALID, "rr_prob must be > 0");
+  if (!(o.rr_prob > 0.0)) return fail(PT_ERR_INVALID, "rr_prob must be > 0");
   memset(&F, 0, sizeof(F));
   F.W = W; F.H = H; F.P = (uint32_t)W * (uint32_t)H;
   for (int k = 0; k < 3; ++k) { F.origin[k] = cam->origin[k]; F.bg[k] = o.bgcolor[k]; }
@@ -409,8 +409,8 @@ static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const Pt
   F.aperture = cam->aperture; F.focus = cam->focus;
   F.seed = seed;
   F.stride = o.spp_stride ? o.spp_stride : 1;
-  F.rr_prob = o.rr_prob; F.rr_min_depth = o.rr_min_depth; F.max_depth = o.max_depth; F.sampling = o.sampling;
-  F.pdf_f = (float)(1 / (2 * M_PI) * (double)o.rr_prob);
+  F.rr_prob = o.rr_prob; F.rr_prob_f = (float)o.rr_prob; F.rr_min_depth = o.rr_min_depth; F.max_depth = o.max_depth; F.sampling = o.sampling;
+  F.pdf_f = (float)(1 / (2 * M_PI) * o.rr_prob);  // camera.cpp:152, narrowed by operator/(vec, scalar)
   F.pi_f = (float)M_PI;
   F.dims_per_vertex = (3u * n_lights + 3u + 1u) & ~1u;
   return PT_OK;
@@ -429,7 +429,7 @@ int pt_device_count(void) {
 
 void pt_options_default(PtOptions *o) {
   if (!o) return;
-  o->rr_prob = 0.7f;      // camera.cpp:118
+  o->rr_prob = .7;        // camera.cpp:118
   o->rr_min_depth = 2;    // camera.cpp:119
   o->max_depth = 0;
   o->sampling = PT_SAMPLE_UNIFORM;
@@ -450,6 +450,8 @@ void pt_camera_default(PtCamera *c) {
 void pt_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
+
+int pt_roulette_pass(double rr_prob, float draw) { return roulette_pass(rr_prob, draw) ? 1 : 0; }
 
 void pt_scene_free(PtScene *s) {
   if (!s) return;

@@ -70,7 +70,8 @@ struct PathFrame {
   uint64_t seed;
   uint32_t sample0;      // global index of the batch's first sample
   uint32_t stride;       // distance between consecutive samples' global indices
-  float rr_prob;
+  double rr_prob;        // camera.cpp:118: a double
+  float rr_prob_f;       // narrowed, for the weight of the cosine-sampling extension
   int rr_min_depth, max_depth, sampling;
   float bg[3];
   float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
@@ -89,7 +90,8 @@ struct FrameDev {
   uint64_t seed;
   uint32_t sample0;      // global index of the batch's first sample
   uint32_t stride;       // distance between consecutive samples' global indices
-  float rr_prob;
+  double rr_prob;        // camera.cpp:118: a double
+  float rr_prob_f;       // narrowed, for the weight of the cosine-sampling extension
   int rr_min_depth, max_depth, sampling;
   float bg[3];
   float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
@@ -317,7 +319,7 @@ __device__ __forceinline__ bool survives(const SceneDev &S, const PathFrame &F, 
   PathRng rng;
   rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
   const uint32_t dim = 2u + (uint32_t)depth * F.dims_per_vertex + 3u * S.n_lights;
-  return (double)rng.real(0.0f, 1.0f, dim) < (double)F.rr_prob;
+  return roulette_pass(F.rr_prob, rng.real(0.0f, 1.0f, dim));
 }
 
 // Closest hit for every queued ray.  The kernel also decides which paths go on after this
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
             if (textured) texel = texel_brdf(S, tex, hit.slot()[i], hit.u()[i], hit.v()[i]);
             if (F.sampling == PT_SAMPLE_COSINE) {
               w = cosine_dir(nrm, rx, ry);
-              T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob);
+              T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob_f);
             } else {
               w = uniform_dir(nrm, rx, ry);
               const V3 brdf = textured ? texel : divs(kd, F.pi_f);                // camera.cpp:122-146

@@ -193,7 +193,7 @@ def test_abi_library_exports_every_declared_symbol():
 
 def test_abi_defaults_are_the_reference_literals():
     o = api.make_options()
-    assert (round(o.rr_prob, 6), o.rr_min_depth, o.max_depth, o.sampling) == (0.7, 2, 0, api.PT_SAMPLE_UNIFORM)
+    assert (o.rr_prob, o.rr_min_depth, o.max_depth, o.sampling) == (0.7, 2, 0, api.PT_SAMPLE_UNIFORM)  # the double .7
     assert list(o.bgcolor) == [0, 0, 0] and o.spp_stride == 1
     c = api.make_camera()
     assert (c.fov_deg, c.vw, c.vh, c.aperture) == (65.0, 1, 1, 0.0)
@@ -201,6 +201,20 @@ def test_abi_defaults_are_the_reference_literals():
     assert out.tolist() == [127.5, 255.0]
     for k in util.GOLD_PHILOX():
         assert [int(x) for x in api.philox(k[0], k[1])] == k[2]
+
+
+def test_roulette_compares_the_float_draw_with_the_double():
+    """camera.cpp:118-119: `randreal(0, 1) < rr_prob` with `constexpr double rr_prob = .7`.  0.7f is
+    0.699999988..., below the double .7, so a draw equal to it continues; the next float up stops.  The
+    product's function (the one the kernels call) and the oracle's agree."""
+    f07 = np.float32(0.7)
+    up = np.nextafter(f07, np.float32(1))
+    L = api.lib()
+    for fn in (lambda p, d: bool(L.pt_roulette_pass(p, d)), O.roulette_pass):
+        assert fn(0.7, float(f07)) is True
+        assert fn(0.7, float(up)) is False
+        assert fn(0.7, 0.0) is True and fn(0.7, 1.0) is False
+        assert fn(float(f07), float(f07)) is False     # a float-rounded probability would stop that path
 
 
 def test_no_device_fails_loudly():
