@@ -14,6 +14,13 @@
  *
  * Threading: one host thread drives one PtScene at a time; distinct PtScene
  * objects (also on distinct devices) may be driven concurrently.
+ * Streams: the calls that take a stream enqueue and return; all of them share the
+ * scene's counter block and path workspace, so a call on another stream than the
+ * scene's previous call first makes its stream wait (hipStreamWaitEvent) for the work
+ * that call left: asynchronous calls on one PtScene run one after the other whatever
+ * streams they name.
+ * Current device: every entry point leaves the calling thread's current HIP device
+ * as it found it.
  */
 #ifndef PTGPU_H
 #define PTGPU_H

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -99,7 +100,33 @@ struct PtScene {
   bool profile = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   PtProfile prof{};
+  // What the launches of the call in progress use: the scene's own workspace and counter block.
+  Workspace *aw = nullptr;
+  uint32_t *acnt = nullptr;
+  // Asynchronous calls share the counter block and the workspace, so work enqueued on a new stream
+  // waits for what the previous call left on the old one.
+  hipEvent_t ev_last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
 };
+
+// Restores the caller's current device when an entry point returns.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static int enter_stream(PtScene *s, hipStream_t st) {
+  if (s->has_last && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->ev_last, 0));
+  return PT_OK;
+}
+static int leave_stream(PtScene *s, hipStream_t st) {
+  HIP_TRY(hipEventRecord(s->ev_last, st));
+  s->last_stream = st;
+  s->has_last = true;
+  return PT_OK;
+}
 
 // LDS stack entries per lane for a tree of the given depth (a few fixed sizes, so that the
 // launch geometry does not change with every scene).
@@ -183,18 +210,28 @@ static void free_workspace(Workspace &w) {
   w = Workspace();
 }
 
-static int ensure_workspace(PtScene *s, size_t cap) {
-  Workspace &w = s->ws;
-  if (w.cap >= cap) return PT_OK;
-  free_workspace(w);
-  const size_t arrays = 2 * 13 + 8 + 3;
-  const size_t stride = (cap + 63) & ~(size_t)63;
+// Bytes of the two parts of a workspace for `stride` paths in flight (stride a multiple of 64):
+// the queues, hit and radiance arrays with the compaction tables, and (split shading only) the
+// visibility-ray arrays: 3 floats per vertex, 6 floats + 1 byte per (vertex, light).
+static const size_t kWsArrays = 2 * 13 + 8 + 3;
+static size_t ws_main_bytes(size_t stride) {
   const size_t n_chunks = stride / 64;
-  if ((n_chunks + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock) return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
-  const size_t extra = n_chunks * 12 + (size_t)kScanBlock * 4 + 256 + stride;
-  HIP_TRY(hipMalloc(&w.block, arrays * stride * sizeof(float) + extra));
-  if (stride > 0x7fffffffu) return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
-  float *p = w.block;
+  return kWsArrays * stride * sizeof(float) + n_chunks * 12 + (size_t)kScanBlock * 4 + 256 + stride;
+}
+static size_t ws_shadow_bytes(size_t stride, uint32_t n_lights, bool split) {
+  if (!split) return 0;
+  const size_t items = stride * n_lights;
+  return (3 * stride + 6 * items) * sizeof(float) + items;
+}
+static size_t ws_stride(size_t cap) { return (cap + 63) & ~(size_t)63; }
+
+// Lays a workspace for `cap` paths out over memory the caller provides.
+static int carve_workspace(Workspace &w, size_t cap, uint32_t n_lights, bool split, float *main_block, float *shadow_block) {
+  const size_t stride = ws_stride(cap);
+  const size_t n_chunks = stride / 64;
+  if ((n_chunks + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock || stride > 0x7fffffffu)
+    return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
+  float *p = main_block;
   for (int k = 0; k < 2; ++k) {
     w.q[k].base = p;
     w.q[k].stride = (uint32_t)stride;
@@ -210,16 +247,12 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
   w.block_tot = w.chunk_base + n_chunks;
   w.alive = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(w.block_tot + kScanBlock) + 63) & ~(uintptr_t)63);
-  if (s->plan.split) {  // split shading: 3 floats per vertex, 6 floats + 1 byte per (vertex, light)
-    const size_t items = stride * s->dev.n_lights;
-    if (hipMalloc(&w.shadow_block, (3 * stride + 6 * items) * sizeof(float) + items) != hipSuccess) {
-      w.shadow_block = nullptr;
-      free_workspace(w);
-      return fail(PT_ERR_NOMEM, "out of device memory for the visibility-ray workspace");
-    }
-    w.sd.vbase = w.shadow_block;
+  w.shadow_items = 0;
+  if (split) {
+    const size_t items = stride * n_lights;
+    w.sd.vbase = shadow_block;
     w.sd.vstride = (uint32_t)stride;
-    w.sd.ibase = w.shadow_block + 3 * stride;
+    w.sd.ibase = shadow_block + 3 * stride;
     w.sd.istride = items;
     w.sd.vis_ = reinterpret_cast<uint8_t *>(w.sd.ibase + 6 * items);
     w.shadow_items = items;
@@ -228,19 +261,44 @@ static int ensure_workspace(PtScene *s, size_t cap) {
   return PT_OK;
 }
 
+static int ensure_workspace(PtScene *s, size_t cap) {
+  Workspace &w = s->ws;
+  if (w.cap >= cap) return PT_OK;
+  free_workspace(w);
+  const size_t stride = ws_stride(cap);
+  if ((stride / 64 + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock || stride > 0x7fffffffu)
+    return fail(PT_ERR_UNSUPPORTED, "too many paths in flight");
+  if (hipMalloc(&w.block, ws_main_bytes(stride)) != hipSuccess) {
+    w.block = nullptr;
+    (void)hipGetLastError();
+    return fail(PT_ERR_NOMEM, "out of device memory for the path workspace");
+  }
+  const size_t sb = ws_shadow_bytes(stride, s->dev.n_lights, s->plan.split);
+  if (sb && hipMalloc(&w.shadow_block, sb) != hipSuccess) {
+    w.shadow_block = nullptr;
+    (void)hipGetLastError();
+    free_workspace(w);
+    return fail(PT_ERR_NOMEM, "out of device memory for the visibility-ray workspace");
+  }
+  return carve_workspace(w, cap, s->dev.n_lights, s->plan.split, w.block, w.shadow_block);
+}
+
 // Dynamic LDS above 64 KiB has to be allowed per kernel once.
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
-  // once per kernel, device and size: the call costs microseconds and a frame has hundreds of launches
-  static thread_local std::vector<std::pair<const void *, unsigned long long>> done;
+  // the attribute is one value per kernel and device: remember the largest one set and raise it only
+  // when a launch needs more (the call costs microseconds and a frame has hundreds of launches)
+  struct Seen { const void *fn; int dev; size_t bytes; };
+  static thread_local std::vector<Seen> done;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   const void *fn = reinterpret_cast<const void *>(kernel);
-  const unsigned long long key = ((unsigned long long)dev << 32) | (unsigned long long)bytes;
-  for (const auto &e : done)
-    if (e.first == fn && e.second == key) return PT_OK;
+  Seen *hit = nullptr;
+  for (auto &e : done)
+    if (e.fn == fn && e.dev == dev) hit = &e;
+  if (hit && hit->bytes >= bytes) return PT_OK;
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  done.emplace_back(fn, key);
+  if (hit) hit->bytes = bytes; else done.push_back(Seen{fn, dev, bytes});
   return PT_OK;
 }
 
@@ -282,7 +340,7 @@ static int launch_trace_queue(PtScene *s, const PathFrame &F, int depth, uint32_
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n, q,
-                       s->ws.hit, s->ws.alive, s->d_cnt + 2, s->d_stats);
+                       s->aw->hit, s->aw->alive, s->acnt + 2, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -293,7 +351,7 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
                         const QueueDev &out, hipStream_t st) {
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    const Workspace &w = s->ws;
+    const Workspace &w = *s->aw;
     const uint32_t kRun = run_length(s->plan, n);
     if (!s->plan.split) {
       const bool tex = s->dev.n_tex != 0;
@@ -302,7 +360,7 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
       int rc = allow_lds(k, s->plan.lds_bytes);
       if (rc != PT_OK) return rc;
       hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, kRun, F, depth, n, in,
-                         w.hit, out, w.sd, w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.rad, s->d_stats);
+                         w.hit, out, w.sd, w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
       HIP_TRY(hipGetLastError());
       return PT_OK;
     }
@@ -310,18 +368,18 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
     if ((size_t)n * s->dev.n_lights > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
     auto ka = k_shade<MODE, BLOCK, COUNT, false, 1, false>;
     hipLaunchKernelGGL(ka, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
-                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.rad, s->d_stats);
+                       w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
     HIP_TRY(hipGetLastError());
     auto kw = s->plan.resident ? k_shadow_walk<MODE, BLOCK, COUNT, true> : k_shadow_walk<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(kw, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     const size_t items = (size_t)n * s->dev.n_lights;
     hipLaunchKernelGGL(kw, grid_for(s->plan, items), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds,
-                       run_length(s->plan, items), n, w.hit, w.sd, s->d_cnt + 5, s->d_stats);
+                       run_length(s->plan, items), n, w.hit, w.sd, s->acnt + 5, s->d_stats);
     HIP_TRY(hipGetLastError());
     auto kb = s->dev.n_tex != 0 ? k_shade<MODE, BLOCK, COUNT, false, 2, true> : k_shade<MODE, BLOCK, COUNT, false, 2, false>;
     hipLaunchKernelGGL(kb, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
-                       w.chunk_mask, w.chunk_base, w.block_tot, s->d_cnt, w.rad, s->d_stats);
+                       w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -331,14 +389,14 @@ template <int MODE, bool COUNT>
 static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz,
                             const float *dx, const float *dy, const float *dz, float *t, int32_t *tri, float *u,
                             float *v, hipStream_t st) {
-  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
     auto k = s->plan.resident ? k_trace_api<MODE, BLOCK, COUNT, true> : k_trace_api<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
-                       dx, dy, dz, t, tri, u, v, s->d_cnt + 2, s->d_stats);
+                       dx, dy, dz, t, tri, u, v, s->acnt + 2, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -347,14 +405,14 @@ static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *
 template <int MODE>
 static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
                           const float *dy, const float *dz, uint8_t *hit, hipStream_t st) {
-  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
     auto k = s->plan.resident ? k_any_api<MODE, BLOCK, true> : k_any_api<MODE, BLOCK, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
-                       dx, dy, dz, hit, s->d_cnt + 2);
+                       dx, dy, dz, hit, s->acnt + 2);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -363,14 +421,14 @@ static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy
 template <int MODE>
 static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
                            const float *dy, const float *dz, int32_t *hits, hipStream_t st) {
-  HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
   return dispatch_plan(s->plan, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
     auto k = s->plan.resident ? k_hits_api<MODE, BLOCK, true> : k_hits_api<MODE, BLOCK, false>;
     int rc = allow_lds(k, s->plan.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
-                       dx, dy, dz, s->d_levels, hits, s->d_cnt + 2);
+                       dx, dy, dz, s->d_levels, hits, s->acnt + 2);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -455,6 +513,7 @@ int pt_roulette_pass(double rr_prob, float draw) { return roulette_pass(rr_prob,
 
 void pt_scene_free(PtScene *s) {
   if (!s) return;
+  DeviceGuard guard;
   (void)hipSetDevice(s->device);
   free_workspace(s->ws);
   if (s->d_nodes) (void)hipFree(s->d_nodes);
@@ -473,10 +532,12 @@ void pt_scene_free(PtScene *s) {
   if (s->h_stats) (void)hipHostFree(s->h_stats);
   for (int k = 0; k < 4; ++k)
     if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+  if (s->ev_last) (void)hipEventDestroy(s->ev_last);
   delete s;
 }
 
 static int upload(PtScene *s, const ptl::FlatScene &f) {
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   auto up = [&](auto **dst, const auto &vec) -> hipError_t {
     const size_t bytes = vec.size() * sizeof(vec[0]);
@@ -499,6 +560,9 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.tri_uv = s->d_tri_uv; s->dev.textures = s->d_textures; s->dev.texels = s->d_texels;
   s->dev.n_tex = (uint32_t)f.textures.size();
   HIP_TRY(hipMalloc(&s->d_cnt, 8 * sizeof(uint32_t)));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming));
+  s->aw = &s->ws;
+  s->acnt = s->d_cnt;
   HIP_TRY(hipMalloc(&s->d_stats, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc(&s->h_cnt, 8 * sizeof(uint32_t), hipHostMallocDefault));
@@ -584,13 +648,17 @@ static int trace_dev(PtScene *s, size_t n, const float *ox, const float *oy, con
                      hipStream_t st) {
   if (n == 0) return PT_OK;
   if (n > ((size_t)1 << 36)) return fail(PT_ERR_INVALID, "too many rays for one call");  // the work-queue head counts chunks of 64 in 32 bits
+  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  int rc = enter_stream(s, st);
+  if (rc != PT_OK) return rc;
   if (mode == PT_TRACE_EXACT)
-    return s->count_stats ? launch_trace_api<PT_TRACE_EXACT, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
-                          : launch_trace_api<PT_TRACE_EXACT, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
-  if (mode == PT_TRACE_FAST)
-    return s->count_stats ? launch_trace_api<PT_TRACE_FAST, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
-                          : launch_trace_api<PT_TRACE_FAST, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
-  return fail(PT_ERR_INVALID, "unknown trace mode");
+    rc = s->count_stats ? launch_trace_api<PT_TRACE_EXACT, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
+                        : launch_trace_api<PT_TRACE_EXACT, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
+  else
+    rc = s->count_stats ? launch_trace_api<PT_TRACE_FAST, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
+                        : launch_trace_api<PT_TRACE_FAST, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
+  if (rc != PT_OK) return rc;
+  return leave_stream(s, st);
 }
 
 int pt_trace_closest_dev(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
@@ -598,11 +666,13 @@ int pt_trace_closest_dev(PtScene *s, size_t n, const float *ox, const float *oy,
                          void *stream) {
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !t || !tri)) return fail(PT_ERR_INVALID, "null ray or result array");
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   return trace_dev(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, mode, (hipStream_t)stream);
 }
 
 static int read_stats4(PtScene *s, uint64_t out[4]) {
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -624,6 +694,7 @@ int pt_scene_read_stats(PtScene *s, uint64_t *node_boxes, uint64_t *tri_tests) {
 
 int pt_scene_profile(PtScene *s, int enable) {
   if (!s) return fail(PT_ERR_INVALID, "null scene");
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   if (enable)
     for (int k = 0; k < 4; ++k)
@@ -644,6 +715,7 @@ int pt_trace_closest(PtScene *s, size_t n, const float *ox, const float *oy, con
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !t || !tri)) return fail(PT_ERR_INVALID, "null ray or result array");
   if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
   float *buf = nullptr;
@@ -676,13 +748,16 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hit)) return fail(PT_ERR_INVALID, "null ray or result array");
   if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
   const size_t m = n < chunk ? n : chunk;
   if (m == 0) return PT_OK;
   float *buf = nullptr;
   HIP_TRY(hipMalloc(&buf, 7 * m * sizeof(float)));
-  int rc = PT_OK;
+  int rc = enter_stream(s, nullptr);
+  if (rc != PT_OK) { (void)hipFree(buf); return rc; }
+  s->has_last = false;  // these calls end with hipDeviceSynchronize: nothing is left in flight
   for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
     const size_t k = (n - off) < chunk ? (n - off) : chunk;
     const float *src[6] = {ox + off, oy + off, oz + off, dx + off, dy + off, dz + off};
@@ -706,13 +781,16 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hits)) return fail(PT_ERR_INVALID, "null ray or result array");
   if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
   const size_t m = n < chunk ? n : chunk;
   if (m == 0) return PT_OK;
   float *buf = nullptr;
   HIP_TRY(hipMalloc(&buf, 7 * m * sizeof(float)));
-  int rc = PT_OK;
+  int rc = enter_stream(s, nullptr);
+  if (rc != PT_OK) { (void)hipFree(buf); return rc; }
+  s->has_last = false;  // these calls end with hipDeviceSynchronize: nothing is left in flight
   for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
     const size_t k = (n - off) < chunk ? (n - off) : chunk;
     const float *src[6] = {ox + off, oy + off, oz + off, dx + off, dy + off, dz + off};
@@ -736,6 +814,7 @@ int pt_camera_rays(const PtCamera *cam, int W, int H, int device, float *dir_xyz
   FrameDev F;
   int rc = make_frame(cam, W, H, 0, nullptr, 0, F);
   if (rc != PT_OK) return rc;
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(device));
   float *d = nullptr;
   const size_t bytes = (size_t)F.P * 3 * sizeof(float);
@@ -749,50 +828,13 @@ int pt_camera_rays(const PtCamera *cam, int W, int H, int device, float *dir_xyz
   return PT_OK;
 }
 
-int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
-                  uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, void *stream) {
-  if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
-  FrameDev F;
-  int rc = make_frame(cam, W, H, seed, opt, s->dev.n_lights, F);
-  if (rc != PT_OK) return rc;
-  PtOptions o;
-  if (opt) o = *opt; else pt_options_default(&o);
-  if (o.trace_mode != PT_TRACE_EXACT && o.trace_mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
-  HIP_TRY(hipSetDevice(s->device));
-  hipStream_t st = (hipStream_t)stream;
-  PtCounters c;
-  memset(&c, 0, sizeof(c));
-  if (spp_count == 0) {
-    if (counters) *counters = c;
-    return PT_OK;
-  }
-  // samples per pixel in flight together, bounded by memory (about 149 bytes per path)
-  uint32_t batch = o.batch_spp;
-  if (batch == 0) {
-    // every batch ends in a long tail of nearly empty passes (half of the 44 passes of a 33-spp
-    // batch of the 1080p room hold under 1 % of its rays), so fewer, larger batches are faster
-    // (64 Mi -> 128 Mi paths in flight: +8 %); a quarter of the free device memory at most
-    uint64_t target = 192ull << 20;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && s->ws.cap == 0) {
-      const uint64_t fit = (uint64_t)free_b / 4 / 152;
-      if (fit < target) target = fit;
-    }
-    if (s->ws.cap > target) target = s->ws.cap;  // a workspace that exists is used in full
-    batch = (uint32_t)(target / F.P);
-  }
-  if (batch > spp_count) batch = spp_count;
-  if (s->plan.split) {
-    // split shading keeps 25 bytes per (vertex, light) pair: at most 24 GB of them
-    const uint64_t per_sample = (uint64_t)F.P * s->dev.n_lights * 25ull;
-    const uint64_t fit = (24ull << 30) / (per_sample ? per_sample : 1);
-    if (batch > fit) batch = (uint32_t)fit;
-  }
-  if (batch < 1) batch = 1;
-  while ((uint64_t)batch * F.P > (1ull << 31) && batch > 1) batch >>= 1;
-  rc = ensure_workspace(s, (size_t)batch * F.P);
-  if (rc != PT_OK) return rc;
-  Workspace &w = s->ws;
+// The frame loop: `batch` samples per pixel in flight together, in the workspace and counter block
+// s->aw / s->acnt point at.
+static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t spp_begin, uint32_t spp_count,
+                          uint32_t batch, float *accum, PtCounters &c, hipStream_t st) {
+  int rc = PT_OK;
+  Workspace &w = *s->aw;
+  uint32_t *cnt = s->acnt;
   const bool exact = o.trace_mode == PT_TRACE_EXACT, cs = s->count_stats;
   const bool prof = s->profile;
   auto elapsed = [&](int a, int b, double &acc) -> int {
@@ -818,21 +860,21 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     int cur = 0;  // q[cur] holds the live paths, q[cur ^ 1] receives the survivors
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
-      HIP_TRY(hipMemsetAsync(s->d_cnt, 0, 8 * sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), st));
       if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
       if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, PF, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, PF, depth, n, w.q[cur], st);
       else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, PF, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, PF, depth, n, w.q[cur], st);
       if (rc != PT_OK) return rc;
       const uint32_t n_chunks = (n + 63) / 64, n_sblocks = (n_chunks + kScanSpan - 1) / kScanSpan;
       hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n, n_chunks, w.alive, w.chunk_mask, w.chunk_base, w.block_tot);
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, s->d_cnt);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, cnt);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
       if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_EXACT, false>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st);
       else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_FAST, false>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st);
       if (rc != PT_OK) return rc;
       if (prof) HIP_TRY(hipEventRecord(s->ev[2], st));
-      HIP_TRY(hipMemcpyAsync(s->h_cnt, s->d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(s->h_cnt, cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       if (prof) {
         if ((rc = elapsed(0, 1, s->prof.trace_ms)) != PT_OK) return rc;
@@ -863,14 +905,81 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
     c.node_boxes = v[0]; c.tri_tests = v[1];
     c.shadow_node_boxes = v[2]; c.shadow_tri_tests = v[3];
   }
-  if (counters) *counters = c;
   return PT_OK;
+}
+
+// Workspace bytes per path in flight for this scene (both parts).
+static uint64_t bytes_per_path(const PtScene *s) {
+  return (uint64_t)(kWsArrays * sizeof(float)) + 2 + (s->plan.split ? 12ull + 25ull * s->dev.n_lights : 0ull);
+}
+
+static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
+                           uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, hipStream_t st) {
+  FrameDev F;
+  int rc = make_frame(cam, W, H, seed, opt, s->dev.n_lights, F);
+  if (rc != PT_OK) return rc;
+  PtOptions o;
+  if (opt) o = *opt; else pt_options_default(&o);
+  if (o.trace_mode != PT_TRACE_EXACT && o.trace_mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  PtCounters c;
+  memset(&c, 0, sizeof(c));
+  if (spp_count == 0) {
+    if (counters) *counters = c;
+    return PT_OK;
+  }
+  const uint64_t per_path = bytes_per_path(s);
+  uint32_t batch = o.batch_spp;
+  {
+    if (batch == 0) {
+      // every batch ends in a long tail of nearly empty passes (half of the 44 passes of a 33-spp
+      // batch of the 1080p room hold under 1 % of its rays), so fewer, larger batches are faster
+      // (64 Mi -> 128 Mi paths in flight: +8 %); a quarter of the free device memory at most,
+      // counting what the present workspace would give back
+      uint64_t target = 192ull << 20;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const uint64_t have = s->ws.cap ? ws_main_bytes(ws_stride(s->ws.cap)) + ws_shadow_bytes(ws_stride(s->ws.cap), s->dev.n_lights, s->plan.split) : 0;
+        const uint64_t fit = ((uint64_t)free_b / 4 + have) / per_path;
+        if (fit < target) target = fit;
+      }
+      if (s->ws.cap > target) target = s->ws.cap;  // a workspace that exists is used in full
+      batch = (uint32_t)(target / F.P);
+    }
+    if (batch > spp_count) batch = spp_count;
+    if (batch < 1) batch = 1;
+    while ((uint64_t)batch * F.P > (1ull << 31) && batch > 1) batch >>= 1;
+    // a failed allocation is retried with half the batch
+    for (;;) {
+      rc = ensure_workspace(s, (size_t)batch * F.P);
+      if (rc != PT_ERR_NOMEM || batch == 1) break;
+      batch = (batch + 1) / 2;
+    }
+    if (rc != PT_OK) return rc;
+    s->aw = &s->ws;
+    s->acnt = s->d_cnt;
+  }
+  rc = enter_stream(s, st);
+  if (rc == PT_OK) rc = render_batches(s, F, o, spp_begin, spp_count, batch, accum, c, st);
+  if (rc == PT_OK) rc = leave_stream(s, st);
+  s->aw = &s->ws;
+  s->acnt = s->d_cnt;
+  if (rc == PT_OK && counters) *counters = c;
+  return rc;
+}
+
+int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
+                  uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, void *stream) {
+  if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(s->device));
+  return render_dev_impl(s, cam, W, H, spp_begin, spp_count, seed, opt, accum, counters, (hipStream_t)stream);
 }
 
 int pt_render(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
               const PtOptions *opt, float *accum, PtCounters *counters) {
   if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
   if (W <= 0 || H <= 0) return fail(PT_ERR_INVALID, "bad image size");
+  DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t bytes = (size_t)W * H * 3 * sizeof(float);
   float *d = nullptr;
