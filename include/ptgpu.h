@@ -253,6 +253,29 @@ int pt_render_dev(PtScene *scene, const PtCamera *cam, int W, int H,
                   const PtOptions *opt, float *accum_rgb_sum_dev,
                   PtCounters *counters, void *stream);
 
+/* Size of the static device buffer pt_render_dev_static works in. */
+#define PT_STATIC_SCRATCH_BYTES (64u << 20)
+
+/*
+ * pt_render_dev for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * Same arguments, same result bit for bit, but no hipMalloc / hipFree or other allocating
+ * call: the counters, path queues, hit records and visibility rays live in a static device
+ * array of PT_STATIC_SCRATCH_BYTES (64 MiB) that every GPU the library runs on holds until
+ * the process ends.  That caps the frame: one sample of every pixel must fit, at about
+ * 150 bytes per pixel (+ 12 + 25 per light for scenes too large for on-chip memory), i.e.
+ * up to about 440 000 pixels (e.g. 800x450; the reference's own 256x256 with 6 samples in
+ * flight); a larger frame is rejected with PT_ERR_UNSUPPORTED and a message naming the sizes.
+ * All scenes on one GPU share that GPU's array and it keeps the last call's contents (the
+ * call clears what must start at zero): calls that overlap in time on one GPU race, whether
+ * on one scene or several; run them one after the other.
+ */
+int pt_render_dev_static(PtScene *scene, const PtCamera *cam, int W, int H,
+                         uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
+                         const PtOptions *opt, float *accum_rgb_sum_dev,
+                         PtCounters *counters, void *stream);
+uint64_t pt_static_scratch_bytes(void);
+
 /* Resolve sums to the reference's pixel values: out = sum / spp * 255
  * (camera.cpp:188-190), host memory, n floats. */
 int pt_resolve(const float *accum_rgb_sum, size_t n, uint32_t spp, float *pixels);

@@ -78,7 +78,7 @@ EXPORTS = [
     "pt_scene_free", "pt_scene_info", "pt_scene_count_stats", "pt_scene_read_stats", "pt_scene_profile",
     "pt_scene_read_profile", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_trace_any", "pt_trace_hits", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
-    "pt_philox4x32", "pt_roulette_pass",
+    "pt_philox4x32", "pt_roulette_pass", "pt_render_dev_static", "pt_static_scratch_bytes",
 ]
 
 
@@ -124,6 +124,8 @@ def lib():
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(PtCamera), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
                                 C.c_uint64, C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtCounters)]
         L.pt_render_dev.argtypes = L.pt_render.argtypes + [C.c_void_p]
+        L.pt_render_dev_static.argtypes = L.pt_render_dev.argtypes
+        L.pt_static_scratch_bytes.restype = C.c_uint64
         L.pt_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         L.pt_philox4x32.argtypes = [C.c_void_p] * 3
         L.pt_philox4x32.restype = None
@@ -346,6 +348,15 @@ class DeviceScene:
         o = opt if opt is not None else make_options()
         _check(lib().pt_render_dev(self._h, C.byref(cam), W, H, spp_begin, spp_count, seed, C.byref(o),
                                    C.c_void_p(accum_ptr), C.byref(cnt), C.c_void_p(stream or 0)))
+        return cnt
+
+    def render_dev_static(self, cam, W, H, spp_count, accum_ptr, spp_begin=0, seed=0, opt=None, stream=None):
+        """render_dev through the entry point that allocates nothing (it works in the library's static
+        device buffer; frames beyond its size raise PtError)."""
+        cnt = PtCounters()
+        o = opt if opt is not None else make_options()
+        _check(lib().pt_render_dev_static(self._h, C.byref(cam), W, H, spp_begin, spp_count, seed, C.byref(o),
+                                          C.c_void_p(accum_ptr), C.byref(cnt), C.c_void_p(stream or 0)))
         return cnt
 
     def trace_closest_dev(self, n, ptrs, out_ptrs, mode=PT_TRACE_FAST, stream=None):

@@ -36,6 +36,12 @@
 
 static thread_local std::string g_err;
 
+// The buffer of pt_render_dev_static: counters, path queues, hit records and visibility rays of a
+// call that may not allocate.  One copy per GPU the library runs on, held until the process ends.
+// Host code never uses this name as an address: static_scratch() returns the device address that
+// hipGetSymbolAddress gave for the device in question.
+static __device__ __align__(256) unsigned char scratch[PT_STATIC_SCRATCH_BYTES];
+
 static int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
@@ -100,7 +106,8 @@ struct PtScene {
   bool profile = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   PtProfile prof{};
-  // What the launches of the call in progress use: the scene's own workspace and counter block.
+  // What the launches of the call in progress use: the scene's own workspace and counter block, or
+  // (pt_render_dev_static) pieces of the library's static device buffer.
   Workspace *aw = nullptr;
   uint32_t *acnt = nullptr;
   // Asynchronous calls share the counter block and the workspace, so work enqueued on a new stream
@@ -109,6 +116,27 @@ struct PtScene {
   hipStream_t last_stream = nullptr;
   bool has_last = false;
 };
+
+// Device address of `scratch` per device ordinal, looked up once per device with that device current
+// (every GPU holds its own copy of the array at its own address).
+static const int kMaxDevices = 64;
+static unsigned char *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mutex;
+
+static int setup_static_scratch(int device) {
+  if (device < 0 || device >= kMaxDevices) return PT_OK;  // such a device simply has no static entry point
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return PT_OK;
+  void *ptr = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+  return PT_OK;
+}
+static unsigned char *static_scratch(int device) {
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  return g_scratch_ptr[device];
+}
 
 // Restores the caller's current device when an entry point returns.
 struct DeviceGuard {
@@ -563,6 +591,10 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming));
   s->aw = &s->ws;
   s->acnt = s->d_cnt;
+  {
+    const int rc = setup_static_scratch(s->device);
+    if (rc != PT_OK) return rc;
+  }
   HIP_TRY(hipMalloc(&s->d_stats, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_stats, 0, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc(&s->h_cnt, 8 * sizeof(uint32_t), hipHostMallocDefault));
@@ -828,8 +860,8 @@ int pt_camera_rays(const PtCamera *cam, int W, int H, int device, float *dir_xyz
   return PT_OK;
 }
 
-// The frame loop: `batch` samples per pixel in flight together, in the workspace and counter block
-// s->aw / s->acnt point at.
+// The frame loop shared by pt_render_dev and pt_render_dev_static: `batch` samples per pixel in flight
+// together, in the workspace and counter block s->aw / s->acnt point at.
 static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t spp_begin, uint32_t spp_count,
                           uint32_t batch, float *accum, PtCounters &c, hipStream_t st) {
   int rc = PT_OK;
@@ -914,7 +946,8 @@ static uint64_t bytes_per_path(const PtScene *s) {
 }
 
 static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
-                           uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, hipStream_t st) {
+                           uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, hipStream_t st,
+                           bool use_static) {
   FrameDev F;
   int rc = make_frame(cam, W, H, seed, opt, s->dev.n_lights, F);
   if (rc != PT_OK) return rc;
@@ -929,7 +962,34 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
   }
   const uint64_t per_path = bytes_per_path(s);
   uint32_t batch = o.batch_spp;
-  {
+  Workspace static_ws;
+  if (use_static) {
+    // everything comes out of the static device buffer: 256 bytes of counters, then the workspace
+    unsigned char *base = static_scratch(s->device);
+    if (!base) return fail(PT_ERR_DEVICE, "the static device buffer was not set up on this device");
+    const uint64_t room = PT_STATIC_SCRATCH_BYTES - 256 - 4096;  // slack for the alignment of the parts
+    uint64_t cap = room / (per_path + 1);
+    cap &= ~63ull;
+    // ws_*_bytes round up in places: shrink until the two parts fit
+    while (cap >= 64 && ws_main_bytes(cap) + 256 + ws_shadow_bytes(cap, s->dev.n_lights, s->plan.split) > room) cap -= 64;
+    if (cap < F.P) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "pt_render_dev_static: a %dx%d frame of this scene needs %llu bytes of workspace per sample "
+                    "in flight, the static buffer holds %llu (at most %llu pixels)", W, H,
+                    (unsigned long long)(per_path * F.P), (unsigned long long)room, (unsigned long long)cap);
+      return fail(PT_ERR_UNSUPPORTED, msg);
+    }
+    const uint32_t fit = (uint32_t)(cap / F.P);
+    if (batch == 0 || batch > fit) batch = fit;
+    if (batch > spp_count) batch = spp_count;
+    const size_t stride = ws_stride((size_t)batch * F.P);
+    float *main_block = reinterpret_cast<float *>(base + 256);
+    float *shadow_block = reinterpret_cast<float *>(base + 256 + ((ws_main_bytes(stride) + 255) & ~(size_t)255));
+    rc = carve_workspace(static_ws, (size_t)batch * F.P, s->dev.n_lights, s->plan.split, main_block, shadow_block);
+    if (rc != PT_OK) return rc;
+    s->aw = &static_ws;
+    s->acnt = reinterpret_cast<uint32_t *>(base);
+  } else {
     if (batch == 0) {
       // every batch ends in a long tail of nearly empty passes (half of the 44 passes of a 33-spp
       // batch of the 1080p room hold under 1 % of its rays), so fewer, larger batches are faster
@@ -972,8 +1032,18 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
   if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
-  return render_dev_impl(s, cam, W, H, spp_begin, spp_count, seed, opt, accum, counters, (hipStream_t)stream);
+  return render_dev_impl(s, cam, W, H, spp_begin, spp_count, seed, opt, accum, counters, (hipStream_t)stream, false);
 }
+
+int pt_render_dev_static(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
+                         uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, void *stream) {
+  if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(s->device));
+  return render_dev_impl(s, cam, W, H, spp_begin, spp_count, seed, opt, accum, counters, (hipStream_t)stream, true);
+}
+
+uint64_t pt_static_scratch_bytes(void) { return PT_STATIC_SCRATCH_BYTES; }
 
 int pt_render(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
               const PtOptions *opt, float *accum, PtCounters *counters) {
