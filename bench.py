@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="box1k")
     ap.add_argument("--spp", type=int, default=0, help="override the configuration's samples per pixel")
-    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact", "fast-binary"],
+                    help="fast-binary: the pruned walk over the reference-shaped trees, for comparison")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented pass (roofline becomes null)")
     ap.add_argument("--max-depth", type=int, default=-1)
@@ -109,7 +110,7 @@ def run_config(name, cfg, mode, max_depth, aperture, steps, warmup, count, rank,
     if aperture >= 0:
         cam_kw.update(aperture=aperture, focus=3.0)
     cam = api.make_camera(**cam_kw)
-    opt_kw = dict(trace_mode=api.PT_TRACE_FAST if mode == "fast" else api.PT_TRACE_EXACT)
+    opt_kw = dict(trace_mode={"fast": api.PT_TRACE_FAST, "exact": api.PT_TRACE_EXACT, "fast-binary": api.PT_TRACE_FAST_BINARY}[mode])
     if max_depth >= 0:
         opt_kw["max_depth"] = max_depth
     if batch_spp > 0:

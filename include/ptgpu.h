@@ -105,8 +105,11 @@ typedef struct PtScene PtScene; /* opaque; owns the device copies */
 
 typedef struct PtSceneInfo {
   uint32_t n_meshes, n_tris, n_lights;
-  uint32_t n_wide_nodes;   /* 64-byte two-child device nodes */
-  uint32_t max_depth;      /* traversal stack entries the deepest ray can need */
+  uint32_t n_wide_nodes;   /* 64-byte two-child device nodes of the reference-shaped tree */
+  uint32_t max_depth;      /* traversal stack entries the deepest ray can need in it */
+  uint32_t n_fast_nodes;   /* 128-byte four-child nodes of the fast mode's own tree */
+  uint32_t fast_max_depth; /* traversal stack entries the deepest ray can need in that one */
+  uint32_t n_gates;        /* internal nodes of the reference's trees (their boxes gate the fast mode's hits) */
   uint32_t device;         /* HIP device ordinal the scene lives on */
   uint64_t device_bytes;   /* bytes of HBM held by the scene */
 } PtSceneInfo;
@@ -124,7 +127,12 @@ typedef struct PtCamera {
 } PtCamera;
 
 enum { PT_SAMPLE_UNIFORM = 0, PT_SAMPLE_COSINE = 1 };
-enum { PT_TRACE_EXACT = 0, PT_TRACE_FAST = 1 };
+/* PT_TRACE_EXACT walks the reference's own trees in the reference's order (no pruning).
+ * PT_TRACE_FAST returns the same hits from a tree of its own (four children per node, surface-area
+ * heuristic), pruned by distance; a hit counts only if the ray passes the reference's box tests above
+ * that triangle.  PT_TRACE_FAST_BINARY is the pruned walk over the reference-shaped trees, kept for
+ * comparison. */
+enum { PT_TRACE_EXACT = 0, PT_TRACE_FAST = 1, PT_TRACE_FAST_BINARY = 2 };
 
 /* Integrator constants.  pt_options_default() fills in the reference literals
  * (camera.cpp:52,118-119,152). */
@@ -136,7 +144,7 @@ typedef struct PtOptions {
                            are traced and lit (k+1 closest-hit passes) and the path ends at depth k */
   int32_t sampling;     /* PT_SAMPLE_UNIFORM (reference) or PT_SAMPLE_COSINE (extension) */
   float bgcolor[3];     /* 0,0,0 */
-  int32_t trace_mode;   /* PT_TRACE_FAST (default) or PT_TRACE_EXACT */
+  int32_t trace_mode;   /* PT_TRACE_FAST (default), PT_TRACE_EXACT or PT_TRACE_FAST_BINARY */
   uint32_t spp_stride;  /* sample k of this call has global index spp_begin + k*spp_stride; 1 */
   uint32_t batch_spp;   /* samples per pixel kept in flight together; 0 = library picks */
 } PtOptions;
@@ -179,6 +187,10 @@ void pt_camera_default(PtCamera *cam);
 int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out);
 void pt_scene_free(PtScene *scene);
 int pt_scene_info(const PtScene *scene, PtSceneInfo *info);
+/* Host only (needs no device): runs the conversion pt_scene_upload would run, verifies the description
+ * and the invariants of the trees built from it (every triangle in exactly one leaf, boxes nested,
+ * references in range) and fills in the counts of `info` (device and device_bytes stay 0; may be null). */
+int pt_scene_check(const PtSceneDesc *desc, PtSceneInfo *info);
 
 /* Work counters (PtCounters.node_boxes / tri_tests): off by default.  When on,
  * separately compiled counting kernels run instead of the plain ones.  They have

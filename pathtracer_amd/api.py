@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptgpu.so")
 
-PT_TRACE_EXACT, PT_TRACE_FAST = 0, 1
+PT_TRACE_EXACT, PT_TRACE_FAST, PT_TRACE_FAST_BINARY = 0, 1, 2
 PT_SAMPLE_UNIFORM, PT_SAMPLE_COSINE = 0, 1
 
 
@@ -40,7 +40,8 @@ class PtSceneDesc(C.Structure):
 
 class PtSceneInfo(C.Structure):
     _fields_ = [("n_meshes", C.c_uint32), ("n_tris", C.c_uint32), ("n_lights", C.c_uint32),
-                ("n_wide_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("device", C.c_uint32),
+                ("n_wide_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("n_fast_nodes", C.c_uint32),
+                ("fast_max_depth", C.c_uint32), ("n_gates", C.c_uint32), ("device", C.c_uint32),
                 ("device_bytes", C.c_uint64)]
 
 
@@ -75,7 +76,7 @@ MAT_DTYPE = np.dtype([("kd", "<f4", 3), ("ke", "<f4", 3)])
 # Every symbol include/ptgpu.h declares.
 EXPORTS = [
     "pt_last_error", "pt_device_count", "pt_options_default", "pt_camera_default", "pt_scene_upload",
-    "pt_scene_free", "pt_scene_info", "pt_scene_count_stats", "pt_scene_read_stats", "pt_scene_profile",
+    "pt_scene_free", "pt_scene_info", "pt_scene_check", "pt_scene_count_stats", "pt_scene_read_stats", "pt_scene_profile",
     "pt_scene_read_profile", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_trace_any", "pt_trace_hits", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
     "pt_philox4x32", "pt_roulette_pass", "pt_render_dev_static", "pt_static_scratch_bytes",
@@ -112,6 +113,7 @@ def lib():
         L.pt_scene_free.argtypes = [C.c_void_p]
         L.pt_scene_free.restype = None
         L.pt_scene_info.argtypes = [C.c_void_p, C.POINTER(PtSceneInfo)]
+        L.pt_scene_check.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtSceneInfo)]
         L.pt_scene_count_stats.argtypes = [C.c_void_p, C.c_int]
         L.pt_scene_read_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pt_scene_profile.argtypes = [C.c_void_p, C.c_int]
@@ -191,6 +193,63 @@ def resolve(accum, spp):
     return out
 
 
+def _make_desc(arrays):
+    """PtSceneDesc over the numpy arrays of `arrays` (see DeviceScene); returns (desc, objects to keep alive)."""
+    a = {
+        "tlas_nodes": np.ascontiguousarray(arrays["tlas_nodes"], NODE_DTYPE),
+        "tlas_order": np.ascontiguousarray(arrays["tlas_order"], np.uint32),
+        "blas_node_offset": np.ascontiguousarray(arrays["blas_node_offset"], np.uint32),
+        "blas_nodes": np.ascontiguousarray(arrays["blas_nodes"], NODE_DTYPE),
+        "tri_offset": np.ascontiguousarray(arrays["tri_offset"], np.uint32),
+        "blas_order": np.ascontiguousarray(arrays["blas_order"], np.uint32),
+        "tri_verts": np.ascontiguousarray(arrays["tri_verts"], np.float32),
+        "mesh_material": np.ascontiguousarray(arrays["mesh_material"], np.uint32),
+        "materials": np.ascontiguousarray(arrays["materials"], MAT_DTYPE),
+    }
+    nm, nt = len(a["mesh_material"]), len(a["blas_order"])
+    if nm == 0 or nt == 0:
+        raise ValueError("empty scene")
+    if len(a["tlas_order"]) != nm or len(a["blas_node_offset"]) != nm + 1 or len(a["tri_offset"]) != nm + 1:
+        raise ValueError("per-mesh arrays disagree in length")
+    if a["tri_verts"].size != nt * 9 or int(a["tri_offset"][-1]) != nt:
+        raise ValueError("triangle arrays disagree in length")
+    if int(a["blas_node_offset"][-1]) != len(a["blas_nodes"]):
+        raise ValueError("blas_node_offset does not end at len(blas_nodes)")
+    d = PtSceneDesc()
+    d.n_meshes = len(a["mesh_material"])
+    d.n_tris = len(a["blas_order"])
+    d.n_materials = len(a["materials"])
+    d.n_tlas_nodes = len(a["tlas_nodes"])
+    for k, v in a.items():
+        setattr(d, k, v.ctypes.data)
+    texs = [np.ascontiguousarray(t, np.uint8) for t in arrays.get("textures", [])]
+    if texs:
+        for t in texs:
+            if t.ndim != 3 or t.shape[2] != 3 or t.size == 0:
+                raise ValueError("a texture must be a non-empty [H,W,3] uint8 array")
+        mt = np.ascontiguousarray(arrays["material_texture"], np.int32)
+        if len(mt) != d.n_materials:
+            raise ValueError("material_texture must have one entry per material")
+        recs = (PtTexture * len(texs))()
+        for r, t in zip(recs, texs):
+            r.width, r.height, r.rgb = t.shape[1], t.shape[0], t.ctypes.data
+        d.n_textures, d.textures, d.material_texture = len(texs), C.addressof(recs), mt.ctypes.data
+        if arrays.get("tri_uv") is not None:
+            uv = np.ascontiguousarray(arrays["tri_uv"], np.float32)
+            if uv.size != nt * 6:
+                raise ValueError("tri_uv must be [n_tris,3,2]")
+            d.tri_uv = uv.ctypes.data
+    return d, (a, texs, locals().get('recs'), locals().get('mt'), locals().get('uv'))
+
+
+def scene_check(arrays):
+    """pt_scene_check: flattens the scene on the host, verifies the trees, returns the counts (no device needed)."""
+    d, keep = _make_desc(arrays)
+    info = PtSceneInfo()
+    _check(lib().pt_scene_check(C.byref(d), C.byref(info)))
+    return {k: int(getattr(info, k)) for k, _ in info._fields_}
+
+
 class DeviceScene:
     """A scene resident in HBM.  `arrays` is a dict with the members of PtSceneDesc as numpy
     arrays (tlas_nodes, tlas_order, blas_node_offset, blas_nodes, tri_offset, blas_order, tri_verts,
@@ -199,50 +258,7 @@ class DeviceScene:
 
     def __init__(self, arrays, device=0):
         self._h = None
-        a = {
-            "tlas_nodes": np.ascontiguousarray(arrays["tlas_nodes"], NODE_DTYPE),
-            "tlas_order": np.ascontiguousarray(arrays["tlas_order"], np.uint32),
-            "blas_node_offset": np.ascontiguousarray(arrays["blas_node_offset"], np.uint32),
-            "blas_nodes": np.ascontiguousarray(arrays["blas_nodes"], NODE_DTYPE),
-            "tri_offset": np.ascontiguousarray(arrays["tri_offset"], np.uint32),
-            "blas_order": np.ascontiguousarray(arrays["blas_order"], np.uint32),
-            "tri_verts": np.ascontiguousarray(arrays["tri_verts"], np.float32),
-            "mesh_material": np.ascontiguousarray(arrays["mesh_material"], np.uint32),
-            "materials": np.ascontiguousarray(arrays["materials"], MAT_DTYPE),
-        }
-        nm, nt = len(a["mesh_material"]), len(a["blas_order"])
-        if nm == 0 or nt == 0:
-            raise ValueError("empty scene")
-        if len(a["tlas_order"]) != nm or len(a["blas_node_offset"]) != nm + 1 or len(a["tri_offset"]) != nm + 1:
-            raise ValueError("per-mesh arrays disagree in length")
-        if a["tri_verts"].size != nt * 9 or int(a["tri_offset"][-1]) != nt:
-            raise ValueError("triangle arrays disagree in length")
-        if int(a["blas_node_offset"][-1]) != len(a["blas_nodes"]):
-            raise ValueError("blas_node_offset does not end at len(blas_nodes)")
-        d = PtSceneDesc()
-        d.n_meshes = len(a["mesh_material"])
-        d.n_tris = len(a["blas_order"])
-        d.n_materials = len(a["materials"])
-        d.n_tlas_nodes = len(a["tlas_nodes"])
-        for k, v in a.items():
-            setattr(d, k, v.ctypes.data)
-        texs = [np.ascontiguousarray(t, np.uint8) for t in arrays.get("textures", [])]
-        if texs:
-            for t in texs:
-                if t.ndim != 3 or t.shape[2] != 3 or t.size == 0:
-                    raise ValueError("a texture must be a non-empty [H,W,3] uint8 array")
-            mt = np.ascontiguousarray(arrays["material_texture"], np.int32)
-            if len(mt) != d.n_materials:
-                raise ValueError("material_texture must have one entry per material")
-            recs = (PtTexture * len(texs))()
-            for r, t in zip(recs, texs):
-                r.width, r.height, r.rgb = t.shape[1], t.shape[0], t.ctypes.data
-            d.n_textures, d.textures, d.material_texture = len(texs), C.addressof(recs), mt.ctypes.data
-            if arrays.get("tri_uv") is not None:
-                uv = np.ascontiguousarray(arrays["tri_uv"], np.float32)
-                if uv.size != nt * 6:
-                    raise ValueError("tri_uv must be [n_tris,3,2]")
-                d.tri_uv = uv.ctypes.data
+        d, self._keep = _make_desc(arrays)
         h = C.c_void_p()
         _check(lib().pt_scene_upload(C.byref(d), device, C.byref(h)))
         self._h = h

@@ -104,6 +104,14 @@ struct SceneDev {
   const uint8_t *texels;
   uint32_t n_tex;                 // 0 when no material has a diffuse map
   uint32_t n_nodes, n_tris, n_lights, n_mats;
+  // the fast mode's own tree (pt_fasttree.cpp): four-child nodes, triangle records in its leaf order,
+  // the global triangle id and texture coordinates per such record, the gate boxes
+  const ptl::Quad4Node *nodes4;
+  const ptl::TriRec4 *tris4;
+  const uint32_t *tri_id4;
+  const ptl::GateBox *gates;
+  const float *tri_uv4;
+  uint32_t n_nodes4, n_tris4, n_gates;
   float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
   uint32_t quorum;      // lanes of a wave that must hold a parked leaf before triangles are tested (closest hit)
   uint32_t quorum_any;  // any-hit walks: the same in 64ths of the wave's unfinished lanes
@@ -125,6 +133,10 @@ struct HitRec {
 // reference never tests, are widened by the flattener for the same reason.)
 #define PT_SLACK_REL 2.44140625e-4f
 #define PT_SLACK_ABS 2.0e-5f
+
+// Which tree a traversal mode walks, and whether it prunes.
+__host__ __device__ constexpr bool mode_prunes(int mode) { return mode != PT_TRACE_EXACT; }
+__host__ __device__ constexpr bool mode_wide(int mode) { return mode == PT_TRACE_FAST; }
 
 // Möller–Trumbore exactly as Triangle::intersect evaluates it (object.cpp:406-429).
 // Returns true when the reference would return a hit.
@@ -225,8 +237,10 @@ __device__ __forceinline__ void stack_put(uint32_t w, uint32_t v) { ((pt_lds_u32
 struct LdsScene {
   uint32_t node_base;  // offset of piece 0 of node 0 in pt_smem, in float4
   uint32_t tri_base;   // offset of piece 0 of triangle 0
+  uint32_t gate_base;  // offset of piece 0 of gate box 0 (fast tree only)
   uint32_t n_nodes;
   uint32_t n_tris;
+  uint32_t n_gates;
   // Traversal stack: the first stack_lds entries of a lane live in LDS; a tree deeper than
   // that spills the rest to this lane's column of a global array (rarely reached: the stack
   // only holds the far child of nodes where both children were hit).
@@ -235,14 +249,12 @@ struct LdsScene {
   uint32_t spill_stride;  // distance between a lane's consecutive spill entries, in words
 };
 
-template <bool RES>
 __device__ __forceinline__ void push_ref(const LdsScene &C, uint32_t stk, uint32_t stride, int sp, uint32_t v) {
-  if (RES || (uint32_t)sp < C.stack_lds) stack_put(stk + (uint32_t)sp * stride, v);
+  if ((uint32_t)sp < C.stack_lds) stack_put(stk + (uint32_t)sp * stride, v);
   else C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride] = v;
 }
-template <bool RES>
 __device__ __forceinline__ uint32_t pop_ref(const LdsScene &C, uint32_t stk, uint32_t stride, int sp) {
-  if (RES || (uint32_t)sp < C.stack_lds) return stack_get(stk + (uint32_t)sp * stride);
+  if ((uint32_t)sp < C.stack_lds) return stack_get(stk + (uint32_t)sp * stride);
   return C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride];
 }
 
@@ -278,12 +290,15 @@ struct RayState {
   int sp;
   bool live;          // cur is valid
   bool found;         // ANY: a triangle was hit
+  // fast tree only: where this ray finds its near and far planes of a node (pieces 2*axis + sign and
+  // 2*axis + 1 - sign): offsets in float4 into the LDS copy (piece * staged nodes) and into a global node
+  uint32_t ln[3], lf[3], gn[3], gf[3];
   HitRec best;
   __device__ __forceinline__ bool done() const { return !live && pend == 0; }
 };
 
 template <int MODE, bool WANT_N>
-__device__ __forceinline__ void walk_init(const SceneDev &S, RayState &st, V3 o, V3 d) {
+__device__ __forceinline__ void walk_init(const SceneDev &S, const LdsScene &C, RayState &st, V3 o, V3 d) {
   // 1/d per axis as AABB::intersect forms it (object.cpp:183).  An axis with d == 0 is
   // skipped there without checking that the origin lies inside the slab; a NaN reciprocal
   // reproduces that (NaN never updates tmin/tmax).  Such a ray then passes every box on that
@@ -293,20 +308,30 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, RayState &st, V3 o,
   // The box is taken S.margin wider for this check (separate origins for the two planes of
   // the slab): node boxes touch triangle edges, and an edge a rounding error away from the
   // ray's plane can still be hit by the reference's triangle test.
-  const float skip = (MODE == PT_TRACE_FAST) ? __builtin_inff() : __builtin_nanf("");
+  const float skip = mode_prunes(MODE) ? __builtin_inff() : __builtin_nanf("");
   st.o = o;
   st.d = d;
   st.ix = d.x != 0.0f ? 1.0f / d.x : skip;
   st.iy = d.y != 0.0f ? 1.0f / d.y : skip;
   st.iz = d.z != 0.0f ? 1.0f / d.z : skip;
-  const float mx = (MODE == PT_TRACE_FAST && d.x == 0.0f) ? S.margin : 0.0f;
-  const float my = (MODE == PT_TRACE_FAST && d.y == 0.0f) ? S.margin : 0.0f;
-  const float mz = (MODE == PT_TRACE_FAST && d.z == 0.0f) ? S.margin : 0.0f;
+  const float mx = (mode_prunes(MODE) && d.x == 0.0f) ? S.margin : 0.0f;
+  const float my = (mode_prunes(MODE) && d.y == 0.0f) ? S.margin : 0.0f;
+  const float mz = (mode_prunes(MODE) && d.z == 0.0f) ? S.margin : 0.0f;
   st.on = mk(o.x + mx, o.y + my, o.z + mz);
   st.of = mk(o.x - mx, o.y - my, o.z - mz);
   st.sx = st.ix < 0.0f;
   st.sy = st.iy < 0.0f;
   st.sz = st.iz < 0.0f;
+  if (mode_wide(MODE)) {
+    const uint32_t s3[3] = {st.sx ? 1u : 0u, st.sy ? 1u : 0u, st.sz ? 1u : 0u};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      st.gn[a] = 2u * a + s3[a];
+      st.gf[a] = 2u * a + 1u - s3[a];
+      st.ln[a] = st.gn[a] * C.n_nodes;
+      st.lf[a] = st.gf[a] * C.n_nodes;
+    }
+  }
   st.best.t = __builtin_inff();
   st.best.slot = 0xffffffffu;
   st.best.rank = 0xffffffffu;
@@ -324,6 +349,56 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, RayState &st, V3 o,
   st.found = false;
 }
 
+// The reference's box test (AABB::intersect, object.cpp:179-195) for the gate of a triangle record of the
+// fast tree: planes as given, the origin as given, an axis with d == 0 skipped (NaN never updates).
+template <bool RES>
+__device__ __forceinline__ bool gate_pass(const SceneDev &S, const LdsScene &C, const RayState &st, uint32_t gate) {
+  if (gate == ptl::NO_GATE) return true;
+  float4 g0, g1;
+  if (RES || gate < C.n_gates) {
+    g0 = lds_f4(C.gate_base + gate);
+    g1 = lds_f4(C.gate_base + C.n_gates + gate);
+  } else {
+    g0 = glb_f4(S.gates, 2u * (size_t)gate);
+    g1 = glb_f4(S.gates, 2u * (size_t)gate + 1);
+  }
+  const float nan = __builtin_nanf("");
+  const float ix = st.d.x != 0.0f ? st.ix : nan, iy = st.d.y != 0.0f ? st.iy : nan, iz = st.d.z != 0.0f ? st.iz : nan;
+  const float ax = ((st.sx ? g1.x : g0.x) - st.o.x) * ix, bx = ((st.sx ? g0.x : g1.x) - st.o.x) * ix;
+  const float ay = ((st.sy ? g1.y : g0.y) - st.o.y) * iy, by = ((st.sy ? g0.y : g1.y) - st.o.y) * iy;
+  const float az = ((st.sz ? g1.z : g0.z) - st.o.z) * iz, bz = ((st.sz ? g0.z : g1.z) - st.o.z) * iz;
+  const float tn = fmaxf(fmaxf(fmaxf(1e-5f, ax), ay), az);
+  const float tf = fminf(fminf(fminf(__builtin_inff(), bx), by), bz);
+  return tf >= tn;
+}
+
+// A triangle hit of a closest-hit walk: it replaces the best one when its t is smaller, or equal with a
+// larger rank (the reference's leftmost-in-leaf / right-sibling rule); in the fast tree only if the ray
+// also passes the triangle's gate.  a, b, c are the three float4 of the triangle's record.
+template <int MODE, bool COUNT, bool WANT_N, bool RES>
+__device__ __forceinline__ void consider_hit(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t &n_boxes, bool hit,
+                                             float t, float u, float v, uint32_t slot, float4 a, float4 b, float4 c) {
+  const uint32_t rank = __float_as_uint(c.w);
+  bool wins = hit && (t < st.best.t || (t == st.best.t && (int32_t)rank > (int32_t)st.best.rank));
+  if (mode_wide(MODE)) {
+    if (wins) {
+      if (COUNT) n_boxes += 1;
+      wins = gate_pass<RES>(S, C, st, __float_as_uint(c.y));
+    }
+  }
+  if (wins) {
+    st.best.t = t;
+    st.best.slot = slot;
+    st.best.rank = rank;
+    st.best.u = u;
+    st.best.v = v;
+    if (WANT_N) {
+      st.best.n = cross(mk(a.w, b.x, b.y), mk(b.z, b.w, c.x));  // (v1-v0) x (v2-v0), object.cpp:393
+      st.best.mat = __float_as_uint(c.z);
+    }
+  }
+}
+
 // One round for the wave: a node step for every lane that has one, then — when enough lanes
 // hold a parked leaf (`quorum` of them for a closest-hit walk) or no lane has node work — the
 // triangle tests of the parked leaves.
@@ -331,58 +406,114 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, RayState &st, V3 o,
 template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES>
 __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
                                            uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
+  constexpr bool PRUNE = mode_prunes(MODE), WIDE = mode_wide(MODE);
   if (st.live && !(st.cur & ptl::REF_LEAF)) {
-    float4 q0, q1, q2;
-    uint4 q3;
-    if (RES || st.cur < C.n_nodes) {
-      const uint32_t at = C.node_base + st.cur;
-      q0 = lds_f4(at); q1 = lds_f4(at + C.n_nodes); q2 = lds_f4(at + 2u * C.n_nodes);
-      const float4 r = lds_f4(at + 3u * C.n_nodes);
-      q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+    const float far = (PRUNE && !ANY) ? st.cull : __builtin_inff();
+    if constexpr (WIDE) {
+      // four children; this ray's near planes of all four come as one float4 per axis, its far planes too
+      float4 nx, fx, ny, fy, nz, fz, rr;
+      if (RES || st.cur < C.n_nodes) {
+        const uint32_t at = C.node_base + st.cur;
+        nx = lds_f4(at + st.ln[0]); fx = lds_f4(at + st.lf[0]);
+        ny = lds_f4(at + st.ln[1]); fy = lds_f4(at + st.lf[1]);
+        nz = lds_f4(at + st.ln[2]); fz = lds_f4(at + st.lf[2]);
+        rr = lds_f4(at + 6u * C.n_nodes);
+      } else {
+        const size_t at = 8u * (size_t)st.cur;
+        nx = glb_f4(S.nodes4, at + st.gn[0]); fx = glb_f4(S.nodes4, at + st.gf[0]);
+        ny = glb_f4(S.nodes4, at + st.gn[1]); fy = glb_f4(S.nodes4, at + st.gf[1]);
+        nz = glb_f4(S.nodes4, at + st.gn[2]); fz = glb_f4(S.nodes4, at + st.gf[2]);
+        rr = glb_f4(S.nodes4, at + 6);
+      }
+      if (COUNT) n_boxes += 4;
+      const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
+      const pt_f2 onx = splat2(st.on.x), ony = splat2(st.on.y), onz = splat2(st.on.z);
+      const pt_f2 ofx = splat2(st.of.x), ofy = splat2(st.of.y), ofz = splat2(st.of.z);
+      const pt_f2 ix = splat2(st.ix), iy = splat2(st.iy), iz = splat2(st.iz);
+      const pt_f2 ax01 = (pair2(nx.x, nx.y) - onx) * ix, ax23 = (pair2(nx.z, nx.w) - onx) * ix;
+      const pt_f2 ay01 = (pair2(ny.x, ny.y) - ony) * iy, ay23 = (pair2(ny.z, ny.w) - ony) * iy;
+      const pt_f2 az01 = (pair2(nz.x, nz.y) - onz) * iz, az23 = (pair2(nz.z, nz.w) - onz) * iz;
+      const pt_f2 bx01 = (pair2(fx.x, fx.y) - ofx) * ix, bx23 = (pair2(fx.z, fx.w) - ofx) * ix;
+      const pt_f2 by01 = (pair2(fy.x, fy.y) - ofy) * iy, by23 = (pair2(fy.z, fy.w) - ofy) * iy;
+      const pt_f2 bz01 = (pair2(fz.x, fz.y) - ofz) * iz, bz23 = (pair2(fz.z, fz.w) - ofz) * iz;
+      // NaN (a plane through the origin of a ray parallel to it) never restricts
+      const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax01.x), ay01.x), az01.x), tf0 = fminf(fminf(fminf(far, bx01.x), by01.x), bz01.x);
+      const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax01.y), ay01.y), az01.y), tf1 = fminf(fminf(fminf(far, bx01.y), by01.y), bz01.y);
+      const float tn2 = fmaxf(fmaxf(fmaxf(1e-5f, ax23.x), ay23.x), az23.x), tf2 = fminf(fminf(fminf(far, bx23.x), by23.x), bz23.x);
+      const float tn3 = fmaxf(fmaxf(fmaxf(1e-5f, ax23.y), ay23.y), az23.y), tf3 = fminf(fminf(fminf(far, bx23.y), by23.y), bz23.y);
+      const bool h0 = tf0 >= tn0, h1 = tf1 >= tn1, h2 = tf2 >= tn2, h3 = tf3 >= tn3;
+      if (h0 || h1 || h2 || h3) {
+        // nearest child next; the others wait on the stack
+        const float inf = __builtin_inff();
+        const float k0 = h0 ? tn0 : inf, k1 = h1 ? tn1 : inf, k2 = h2 ? tn2 : inf, k3 = h3 ? tn3 : inf;
+        const float km = fminf(fminf(k0, k1), fminf(k2, k3));
+        const bool c0 = h0 && k0 == km;
+        const bool c1 = !c0 && h1 && k1 == km;
+        const bool c2 = !c0 && !c1 && h2 && k2 == km;
+        const bool c3 = !c0 && !c1 && !c2;
+        if (h3 && !c3) { push_ref(C, stk, stride, st.sp, r3); ++st.sp; }
+        if (h2 && !c2) { push_ref(C, stk, stride, st.sp, r2); ++st.sp; }
+        if (h1 && !c1) { push_ref(C, stk, stride, st.sp, r1); ++st.sp; }
+        if (h0 && !c0) { push_ref(C, stk, stride, st.sp, r0); ++st.sp; }
+        st.cur = c0 ? r0 : (c1 ? r1 : (c2 ? r2 : r3));
+      } else if (st.sp == 0) {
+        st.live = false;
+      } else {
+        --st.sp;
+        st.cur = pop_ref(C, stk, stride, st.sp);
+      }
     } else {
-      const size_t at = 4u * (size_t)st.cur;
-      q0 = glb_f4(S.nodes, at); q1 = glb_f4(S.nodes, at + 1); q2 = glb_f4(S.nodes, at + 2);
-      const float4 r = glb_f4(S.nodes, at + 3);
-      q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
-    }
-    if (COUNT) n_boxes += 2;
-    // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
-    const float far = (MODE == PT_TRACE_FAST && !ANY) ? st.cull : __builtin_inff();
-    // both children side by side in packed pairs: (plane - origin) * (1/d), object.cpp:184-185
-    const pt_f2 ax = (pair2(st.sx ? q0.w : q0.x, st.sx ? q2.y : q1.z) - splat2(st.on.x)) * splat2(st.ix);
-    const pt_f2 bx = (pair2(st.sx ? q0.x : q0.w, st.sx ? q1.z : q2.y) - splat2(st.of.x)) * splat2(st.ix);
-    const pt_f2 ay = (pair2(st.sy ? q1.x : q0.y, st.sy ? q2.z : q1.w) - splat2(st.on.y)) * splat2(st.iy);
-    const pt_f2 by = (pair2(st.sy ? q0.y : q1.x, st.sy ? q1.w : q2.z) - splat2(st.of.y)) * splat2(st.iy);
-    const pt_f2 az = (pair2(st.sz ? q1.y : q0.z, st.sz ? q2.w : q2.x) - splat2(st.on.z)) * splat2(st.iz);
-    const pt_f2 bz = (pair2(st.sz ? q0.z : q1.y, st.sz ? q2.x : q2.w) - splat2(st.of.z)) * splat2(st.iz);
-    // tmin starts at EPSILON, tmax at the cull distance; NaN never updates (object.cpp:180,188-191)
-    const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax.x), ay.x), az.x), tf0 = fminf(fminf(fminf(far, bx.x), by.x), bz.x);
-    const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax.y), ay.y), az.y), tf1 = fminf(fminf(fminf(far, bx.y), by.y), bz.y);
-    bool p0, p1;
-    if (MODE == PT_TRACE_EXACT) {
-      // only an internal node of the reference tree is box-tested there (object.cpp:277)
-      p0 = (q3.z == KIND_INTERNAL) ? (tf0 >= tn0) : true;
-      p1 = (q3.w == KIND_INTERNAL) ? (tf1 >= tn1) : true;
-    } else {
-      // leaf and group boxes were widened by the flattener, and tf started at the cull
-      // distance, so one comparison covers the box test and the pruning
-      p0 = tf0 >= tn0;
-      p1 = tf1 >= tn1;
-    }
-    if (p0 && p1) {
-      const bool swap = (MODE == PT_TRACE_FAST) ? (tn1 < tn0) : false;  // near child first (an any-hit walk ends sooner too)
-      push_ref<RES>(C, stk, stride, st.sp, swap ? q3.x : q3.y);
-      ++st.sp;
-      st.cur = swap ? q3.y : q3.x;
-    } else if (p0) {
-      st.cur = q3.x;
-    } else if (p1) {
-      st.cur = q3.y;
-    } else if (st.sp == 0) {
-      st.live = false;
-    } else {
-      --st.sp;
-      st.cur = pop_ref<RES>(C, stk, stride, st.sp);
+      float4 q0, q1, q2;
+      uint4 q3;
+      if (RES || st.cur < C.n_nodes) {
+        const uint32_t at = C.node_base + st.cur;
+        q0 = lds_f4(at); q1 = lds_f4(at + C.n_nodes); q2 = lds_f4(at + 2u * C.n_nodes);
+        const float4 r = lds_f4(at + 3u * C.n_nodes);
+        q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+      } else {
+        const size_t at = 4u * (size_t)st.cur;
+        q0 = glb_f4(S.nodes, at); q1 = glb_f4(S.nodes, at + 1); q2 = glb_f4(S.nodes, at + 2);
+        const float4 r = glb_f4(S.nodes, at + 3);
+        q3 = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+      }
+      if (COUNT) n_boxes += 2;
+      // child 0: lo = q0.xyz, hi = (q0.w, q1.x, q1.y); child 1: lo = (q1.z, q1.w, q2.x), hi = q2.yzw
+      // both children side by side in packed pairs: (plane - origin) * (1/d), object.cpp:184-185
+      const pt_f2 ax = (pair2(st.sx ? q0.w : q0.x, st.sx ? q2.y : q1.z) - splat2(st.on.x)) * splat2(st.ix);
+      const pt_f2 bx = (pair2(st.sx ? q0.x : q0.w, st.sx ? q1.z : q2.y) - splat2(st.of.x)) * splat2(st.ix);
+      const pt_f2 ay = (pair2(st.sy ? q1.x : q0.y, st.sy ? q2.z : q1.w) - splat2(st.on.y)) * splat2(st.iy);
+      const pt_f2 by = (pair2(st.sy ? q0.y : q1.x, st.sy ? q1.w : q2.z) - splat2(st.of.y)) * splat2(st.iy);
+      const pt_f2 az = (pair2(st.sz ? q1.y : q0.z, st.sz ? q2.w : q2.x) - splat2(st.on.z)) * splat2(st.iz);
+      const pt_f2 bz = (pair2(st.sz ? q0.z : q1.y, st.sz ? q2.x : q2.w) - splat2(st.of.z)) * splat2(st.iz);
+      // tmin starts at EPSILON, tmax at the cull distance; NaN never updates (object.cpp:180,188-191)
+      const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax.x), ay.x), az.x), tf0 = fminf(fminf(fminf(far, bx.x), by.x), bz.x);
+      const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax.y), ay.y), az.y), tf1 = fminf(fminf(fminf(far, bx.y), by.y), bz.y);
+      bool p0, p1;
+      if (!PRUNE) {
+        // only an internal node of the reference tree is box-tested there (object.cpp:277)
+        p0 = (q3.z == KIND_INTERNAL) ? (tf0 >= tn0) : true;
+        p1 = (q3.w == KIND_INTERNAL) ? (tf1 >= tn1) : true;
+      } else {
+        // leaf and group boxes were widened by the flattener, and tf started at the cull
+        // distance, so one comparison covers the box test and the pruning
+        p0 = tf0 >= tn0;
+        p1 = tf1 >= tn1;
+      }
+      if (p0 && p1) {
+        const bool swap = PRUNE ? (tn1 < tn0) : false;  // near child first (an any-hit walk ends sooner too)
+        push_ref(C, stk, stride, st.sp, swap ? q3.x : q3.y);
+        ++st.sp;
+        st.cur = swap ? q3.y : q3.x;
+      } else if (p0) {
+        st.cur = q3.x;
+      } else if (p1) {
+        st.cur = q3.y;
+      } else if (st.sp == 0) {
+        st.live = false;
+      } else {
+        --st.sp;
+        st.cur = pop_ref(C, stk, stride, st.sp);
+      }
     }
   }
   if (st.live && (st.cur & ptl::REF_LEAF) && st.pend == 0) {  // park the leaf, go on with the next node
@@ -391,7 +522,7 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
       st.live = false;
     } else {
       --st.sp;
-      st.cur = pop_ref<RES>(C, stk, stride, st.sp);
+      st.cur = pop_ref(C, stk, stride, st.sp);
     }
   }
   const unsigned long long m_pend = __ballot(st.pend != 0);
@@ -408,6 +539,7 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
       const uint32_t cnt = ((st.pend >> 28) & 7u) + 1u;
       st.pend = 0;
       const bool in_lds = RES || first + cnt <= C.n_tris;
+      const void *gtris = WIDE ? (const void *)S.tris4 : (const void *)S.tris;
       for (uint32_t k = 0; k < cnt; k += 2) {
         // an odd last triangle is paired with itself and its second copy ignored
         const bool two = k + 1 < cnt;
@@ -420,36 +552,28 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
           a1 = lds_f4(at1); b1 = lds_f4(at1 + C.n_tris); c1 = lds_f4(at1 + 2u * C.n_tris);
         } else {
           const size_t at0 = 3u * (size_t)s0, at1 = 3u * (size_t)s1;
-          a0 = glb_f4(S.tris, at0); b0 = glb_f4(S.tris, at0 + 1); c0 = glb_f4(S.tris, at0 + 2);
-          a1 = glb_f4(S.tris, at1); b1 = glb_f4(S.tris, at1 + 1); c1 = glb_f4(S.tris, at1 + 2);
+          a0 = glb_f4(gtris, at0); b0 = glb_f4(gtris, at0 + 1); c0 = glb_f4(gtris, at0 + 2);
+          a1 = glb_f4(gtris, at1); b1 = glb_f4(gtris, at1 + 1); c1 = glb_f4(gtris, at1 + 2);
         }
         bool h0, h1;
         pt_f2 t2, u2, v2;
         tri_test2(a0, b0, c0, a1, b1, c1, st.o, st.d, h0, h1, t2, u2, v2);
         h1 = h1 && two;
         if (ANY) {
+          if (WIDE) {
+            // a hit counts only where the reference reaches that triangle's leaf
+            if (h0) { h0 = gate_pass<RES>(S, C, st, __float_as_uint(c0.y)); if (COUNT) n_boxes += 1; }
+            if (h1 && !h0) { h1 = gate_pass<RES>(S, C, st, __float_as_uint(c1.y)); if (COUNT) n_boxes += 1; }
+          }
           if (h0 || h1) {
             st.found = true;
             st.live = false;
             break;
           }
         } else {
-          // larger rank wins a tie: the reference's leftmost-in-leaf / right-sibling rule
-          if (h0 && (t2.x < st.best.t || (t2.x == st.best.t && (int32_t)__float_as_uint(c0.w) > (int32_t)st.best.rank))) {
-            st.best.t = t2.x; st.best.slot = s0; st.best.rank = __float_as_uint(c0.w); st.best.u = u2.x; st.best.v = v2.x;
-            if (WANT_N) {
-              st.best.n = cross(mk(a0.w, b0.x, b0.y), mk(b0.z, b0.w, c0.x));  // (v1-v0) x (v2-v0), object.cpp:393
-              st.best.mat = __float_as_uint(c0.z);
-            }
-          }
-          if (h1 && (t2.y < st.best.t || (t2.y == st.best.t && (int32_t)__float_as_uint(c1.w) > (int32_t)st.best.rank))) {
-            st.best.t = t2.y; st.best.slot = s1; st.best.rank = __float_as_uint(c1.w); st.best.u = u2.y; st.best.v = v2.y;
-            if (WANT_N) {
-              st.best.n = cross(mk(a1.w, b1.x, b1.y), mk(b1.z, b1.w, c1.x));
-              st.best.mat = __float_as_uint(c1.z);
-            }
-          }
-          if (MODE == PT_TRACE_FAST) st.cull = st.best.t + (st.best.t * PT_SLACK_REL + PT_SLACK_ABS);
+          consider_hit<MODE, COUNT, WANT_N, RES>(S, C, st, n_boxes, h0, t2.x, u2.x, v2.x, s0, a0, b0, c0);
+          consider_hit<MODE, COUNT, WANT_N, RES>(S, C, st, n_boxes, h1, t2.y, u2.y, v2.y, s1, a1, b1, c1);
+          if (PRUNE) st.cull = st.best.t + (st.best.t * PT_SLACK_REL + PT_SLACK_ABS);
         }
       }
     }
@@ -461,7 +585,7 @@ template <int MODE, bool ANY, bool COUNT, bool WANT_N = false, bool RES = false>
 __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o, V3 d, uint32_t stk, uint32_t stride,
                                      HitRec &best, uint32_t &n_boxes, uint32_t &n_tris) {
   RayState st;
-  walk_init<MODE, WANT_N>(S, st, o, d);
+  walk_init<MODE, WANT_N>(S, C, st, o, d);
   do {
     walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, S.quorum);
   } while (__ballot(!st.done()) != 0);

@@ -1,0 +1,408 @@
+// pt_fasttree.cpp — the fast traversal mode's own tree.
+//
+// The reference's recursive BVH::intersect (object.cpp:265-285) defines WHICH triangle a ray returns:
+// the hit of smallest t (ties by position, carried as TriRec::rank) among the triangles of the leaves it
+// reaches, and it reaches a leaf exactly when the ray passes the own-box test of every internal node
+// above it.  The boxes of a tree are nested (a node's box is the exact min/max of its children's,
+// object.cpp:296-308) and AABB::intersect (object.cpp:179-195) is monotone under nesting — a larger box
+// gives t0' <= t0 and t1' >= t1 in the same rounded arithmetic — so passing the box of the LOWEST internal
+// node above a leaf implies passing all the ones above it.  That lowest box is the triangle's "gate".
+//
+// Hence the fast mode is free to find candidate triangles with any structure it likes, as long as it
+// (a) never misses a triangle whose computed hit could win and (b) accepts a hit only when the ray passes
+// the triangle's gate, tested with the reference's arithmetic.  This file builds that structure: one tree
+// over all triangles of the scene (no top-level / per-mesh split), binned surface-area heuristic, leaves
+// of at most two triangles (the kernels test triangles in packed pairs), collapsed to four children per
+// node.  Every box is widened by a margin, because a triangle's computed hit can lie a few rounding
+// errors outside its exact bounds.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+
+#include "pt_flatten.h"
+
+namespace ptl {
+namespace {
+
+struct Box3 {
+  float lo[3], hi[3];
+  void clear() {
+    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+  }
+  void grow(const Box3 &b) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+  }
+  float area() const {
+    const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    if (!(x >= 0 && y >= 0 && z >= 0)) return 0;
+    return x * y + y * z + z * x;
+  }
+};
+
+struct BinNode {
+  Box3 box;
+  uint32_t left = 0, right = 0;   // children (internal) ...
+  uint32_t first = 0, count = 0;  // ... or a range of `order` (count > 0: leaf)
+};
+
+struct FastBuilder {
+  const PtSceneDesc &d;
+  FlatScene &out;
+  uint32_t n = 0;                 // real triangles (records of out.tris without the degenerate one)
+  std::vector<Box3> pb;           // per record of out.tris: exact bounds of its vertices
+  std::vector<float> cen;         // 3 per record: box centre
+  std::vector<uint32_t> order;    // permutation of records, leaves are ranges of it
+  std::vector<BinNode> bn;
+
+  FastBuilder(const PtSceneDesc &dd, FlatScene &o) : d(dd), out(o) {}
+
+  static const int kBins = 16;
+
+  Box3 range_box(uint32_t lo, uint32_t hi) const {
+    Box3 b;
+    b.clear();
+    for (uint32_t i = lo; i < hi; ++i) b.grow(pb[order[i]]);
+    return b;
+  }
+
+  // Splits order[lo, hi) and returns the first index of the right part.
+  uint32_t split(uint32_t lo, uint32_t hi) {
+    const uint32_t cnt = hi - lo;
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = lo; i < hi; ++i)
+      for (int k = 0; k < 3; ++k) {
+        const float c = cen[3 * (size_t)order[i] + k];
+        if (c < cmin[k]) cmin[k] = c;
+        if (c > cmax[k]) cmax[k] = c;
+      }
+    if (cnt <= 16) {
+      // few triangles: exact sweep along every axis; the left part gets an even number of triangles so
+      // that leaves come out as pairs
+      float best = INFINITY;
+      int best_axis = -1;
+      uint32_t best_k = 0;
+      std::vector<uint32_t> tmp(order.begin() + lo, order.begin() + hi), best_order;
+      std::vector<float> right_area(cnt + 1);
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!(cmax[axis] > cmin[axis])) continue;
+        std::stable_sort(tmp.begin(), tmp.end(), [&](uint32_t a, uint32_t b) { return cen[3 * (size_t)a + axis] < cen[3 * (size_t)b + axis]; });
+        Box3 b;
+        b.clear();
+        for (uint32_t k = cnt; k-- > 0;) {
+          b.grow(pb[tmp[k]]);
+          right_area[k] = b.area();
+        }
+        b.clear();
+        for (uint32_t k = 1; k < cnt; ++k) {
+          b.grow(pb[tmp[k - 1]]);
+          if (k & 1u) continue;
+          const float cost = b.area() * (float)k + right_area[k] * (float)(cnt - k);
+          if (cost < best) {
+            best = cost;
+            best_axis = axis;
+            best_k = k;
+            best_order = tmp;
+          }
+        }
+      }
+      if (best_axis < 0) {  // cnt == 3, or all centres equal
+        uint32_t k = cnt >= 4 ? (cnt / 2) & ~1u : (cnt == 3 ? 2u : 1u);
+        return lo + k;
+      }
+      std::copy(best_order.begin(), best_order.end(), order.begin() + lo);
+      return lo + best_k;
+    }
+    float best = INFINITY;
+    int best_axis = -1, best_bin = 0;
+    for (int axis = 0; axis < 3; ++axis) {
+      const float ext = cmax[axis] - cmin[axis];
+      if (!(ext > 0) || !std::isfinite(ext)) continue;
+      Box3 bb[kBins];
+      uint32_t bc[kBins];
+      for (int b = 0; b < kBins; ++b) { bb[b].clear(); bc[b] = 0; }
+      const float scale = (float)kBins / ext;
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t id = order[i];
+        int b = (int)((cen[3 * (size_t)id + axis] - cmin[axis]) * scale);
+        b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+        bb[b].grow(pb[id]);
+        ++bc[b];
+      }
+      float ra[kBins];
+      uint32_t rc[kBins];
+      Box3 acc;
+      acc.clear();
+      uint32_t c = 0;
+      for (int b = kBins - 1; b > 0; --b) {
+        acc.grow(bb[b]);
+        c += bc[b];
+        ra[b] = acc.area();
+        rc[b] = c;
+      }
+      acc.clear();
+      c = 0;
+      for (int b = 0; b + 1 < kBins; ++b) {
+        acc.grow(bb[b]);
+        c += bc[b];
+        if (c == 0 || rc[b + 1] == 0) continue;
+        const float cost = acc.area() * (float)c + ra[b + 1] * (float)rc[b + 1];
+        if (cost < best) {
+          best = cost;
+          best_axis = axis;
+          best_bin = b;
+        }
+      }
+    }
+    if (best_axis < 0) return lo + cnt / 2;  // all centres (nearly) equal, or non-finite: halves
+    const float ext = cmax[best_axis] - cmin[best_axis];
+    const float scale = (float)kBins / ext;
+    auto mid = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t id) {
+      int b = (int)((cen[3 * (size_t)id + best_axis] - cmin[best_axis]) * scale);
+      b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+      return b <= best_bin;
+    });
+    uint32_t m = (uint32_t)(mid - order.begin());
+    if (m == lo || m == hi) m = lo + cnt / 2;
+    return m;
+  }
+
+  void build_binary() {
+    bn.clear();
+    bn.reserve((size_t)n + 16);
+    struct Job { uint32_t node, lo, hi; };
+    std::vector<Job> jobs;
+    bn.push_back(BinNode());
+    jobs.push_back(Job{0, 0, n});
+    while (!jobs.empty()) {
+      const Job j = jobs.back();
+      jobs.pop_back();
+      bn[j.node].box = range_box(j.lo, j.hi);
+      if (j.hi - j.lo <= 2) {
+        bn[j.node].first = j.lo;
+        bn[j.node].count = j.hi - j.lo;
+        continue;
+      }
+      const uint32_t m = split(j.lo, j.hi);
+      const uint32_t l = (uint32_t)bn.size();
+      bn.push_back(BinNode());
+      bn.push_back(BinNode());
+      bn[j.node].left = l;
+      bn[j.node].right = l + 1;
+      jobs.push_back(Job{l + 1, m, j.hi});
+      jobs.push_back(Job{l, j.lo, m});
+    }
+  }
+
+  // Collapses the binary tree into four-child nodes (creation order; renumbered afterwards) and lays
+  // the triangle records out in leaf order.
+  struct Wide {
+    uint32_t child[4];
+    int n_child;
+  };
+  std::vector<Wide> wide;          // child = index into bn
+  std::vector<uint32_t> wide_of;   // per binary node that heads a wide node: its index in `wide`
+
+  void collapse() {
+    wide.clear();
+    wide_of.assign(bn.size(), 0xffffffffu);
+    std::vector<uint32_t> todo;
+    todo.push_back(0);
+    while (!todo.empty()) {
+      const uint32_t b = todo.back();
+      todo.pop_back();
+      Wide w;
+      w.n_child = 2;
+      w.child[0] = bn[b].left;
+      w.child[1] = bn[b].right;
+      while (w.n_child < 4) {
+        int pick = -1;
+        float best = -1;
+        for (int k = 0; k < w.n_child; ++k) {
+          const BinNode &c = bn[w.child[k]];
+          if (c.count > 0) continue;
+          const float a = c.box.area();
+          if (a > best) {
+            best = a;
+            pick = k;
+          }
+        }
+        if (pick < 0) break;
+        const uint32_t c = w.child[pick];
+        w.child[pick] = bn[c].left;
+        w.child[w.n_child++] = bn[c].right;
+      }
+      wide_of[b] = (uint32_t)wide.size();
+      wide.push_back(w);
+      for (int k = 0; k < w.n_child; ++k)
+        if (bn[w.child[k]].count == 0) todo.push_back(w.child[k]);
+    }
+  }
+
+  void emit() {
+    const float margin = out.margin_rel * out.max_abs_coord + 2.0e-5f;
+    // order of the wide nodes: the top of the tree breadth-first (those are the ones kept in LDS), the
+    // rest depth-first
+    const uint32_t kTop = 1280;
+    std::vector<uint32_t> seq;
+    seq.reserve(wide.size());
+    std::deque<uint32_t> q;
+    q.push_back(0);
+    auto kids = [&](uint32_t wi, uint32_t k[4]) {
+      int c = 0;
+      for (int j = 0; j < wide[wi].n_child; ++j)
+        if (bn[wide[wi].child[j]].count == 0) k[c++] = wide_of[wide[wi].child[j]];
+      return c;
+    };
+    while (!q.empty() && seq.size() < kTop) {
+      const uint32_t wi = q.front();
+      q.pop_front();
+      seq.push_back(wi);
+      uint32_t k[4];
+      const int c = kids(wi, k);
+      for (int j = 0; j < c; ++j) q.push_back(k[j]);
+    }
+    std::vector<uint32_t> st;
+    for (uint32_t start : q) {
+      st.push_back(start);
+      while (!st.empty()) {
+        const uint32_t wi = st.back();
+        st.pop_back();
+        seq.push_back(wi);
+        uint32_t k[4];
+        const int c = kids(wi, k);
+        for (int j = c - 1; j >= 0; --j) st.push_back(k[j]);
+      }
+    }
+    std::vector<uint32_t> newidx(wide.size(), 0);
+    for (uint32_t j = 0; j < seq.size(); ++j) newidx[seq[j]] = j;
+
+    // triangle records in the order the leaves are met
+    out.tris4.clear();
+    out.tri_id4.clear();
+    out.tris4.reserve((size_t)n + 1);
+    out.tri_id4.reserve((size_t)n + 1);
+    auto put = [&](uint32_t rec) {
+      const TriRec &r = out.tris[rec];
+      TriRec4 q;
+      for (int k = 0; k < 3; ++k) { q.v0[k] = r.v0[k]; q.e1[k] = r.e1[k]; q.e2[k] = r.e2[k]; }
+      q.gate = out.tri_gate[rec];
+      q.mat_id = r.mat_id;
+      q.rank = r.rank;
+      out.tris4.push_back(q);
+      out.tri_id4.push_back(r.tri_id);
+    };
+    std::vector<uint32_t> leaf_first(bn.size(), 0);
+    for (uint32_t j = 0; j < seq.size(); ++j) {
+      const Wide &w = wide[seq[j]];
+      for (int k = 0; k < w.n_child; ++k) {
+        const BinNode &c = bn[w.child[k]];
+        if (c.count == 0) continue;
+        leaf_first[w.child[k]] = (uint32_t)out.tris4.size();
+        for (uint32_t t = 0; t < c.count; ++t) {
+          put(order[c.first + t]);
+        }
+      }
+    }
+    const uint32_t filler = (uint32_t)out.tris4.size();
+    put(n);  // the degenerate triangle no ray hits
+
+    out.nodes4.assign(seq.size(), Quad4Node());
+    for (uint32_t j = 0; j < seq.size(); ++j) {
+      const Wide &w = wide[seq[j]];
+      Quad4Node &o = out.nodes4[j];
+      memset(&o, 0, sizeof(o));
+      for (int k = 0; k < 4; ++k) {
+        if (k >= w.n_child) {
+          o.lox[k] = o.loy[k] = o.loz[k] = INFINITY;
+          o.hix[k] = o.hiy[k] = o.hiz[k] = -INFINITY;
+          o.ref[k] = REF_LEAF | filler;
+          continue;
+        }
+        const BinNode &c = bn[w.child[k]];
+        o.lox[k] = c.box.lo[0] - margin; o.hix[k] = c.box.hi[0] + margin;
+        o.loy[k] = c.box.lo[1] - margin; o.hiy[k] = c.box.hi[1] + margin;
+        o.loz[k] = c.box.lo[2] - margin; o.hiz[k] = c.box.hi[2] + margin;
+        if (c.count > 0) o.ref[k] = REF_LEAF | ((c.count - 1) << 28) | leaf_first[w.child[k]];
+        else o.ref[k] = newidx[wide_of[w.child[k]]];
+      }
+    }
+
+    // depth of the wide tree -> stack entries a descent can need (up to three siblings left behind per level)
+    uint32_t deepest = 1;
+    {
+      std::vector<std::pair<uint32_t, uint32_t>> walk;  // node, depth
+      walk.push_back(std::make_pair(0u, 1u));
+      while (!walk.empty()) {
+        const std::pair<uint32_t, uint32_t> e = walk.back();
+        walk.pop_back();
+        if (e.second > deepest) deepest = e.second;
+        const Quad4Node &o = out.nodes4[e.first];
+        for (int k = 0; k < 4; ++k)
+          if (!(o.ref[k] & REF_LEAF)) walk.push_back(std::make_pair(o.ref[k], e.second + 1));
+      }
+    }
+    out.max_depth4 = 3 * deepest + 2;
+
+    if (!out.tri_uv.empty()) {
+      out.tri_uv4.assign(out.tris4.size() * 6, 0.0f);
+      for (size_t s = 0; s < out.tris4.size(); ++s) {
+        const uint32_t gid = out.tri_id4[s];
+        if (gid == 0xffffffffu) continue;
+        for (int k = 0; k < 6; ++k) out.tri_uv4[s * 6 + k] = d.tri_uv[(size_t)gid * 6 + k];
+      }
+    }
+  }
+
+  void run() {
+    n = (uint32_t)out.tris.size() - 1;  // the last record is the degenerate filler
+    pb.resize(n);
+    cen.resize(3 * (size_t)n);
+    order.resize(n);
+    for (uint32_t s = 0; s < n; ++s) {
+      const float *p = d.tri_verts + (size_t)out.tris[s].tri_id * 9;
+      Box3 b;
+      b.clear();
+      for (int v = 0; v < 3; ++v)
+        for (int k = 0; k < 3; ++k) {
+          const float x = p[3 * v + k];
+          if (x < b.lo[k]) b.lo[k] = x;   // NaN coordinates leave the box alone
+          if (x > b.hi[k]) b.hi[k] = x;
+        }
+      pb[s] = b;
+      for (int k = 0; k < 3; ++k) {
+        const float c = 0.5f * b.lo[k] + 0.5f * b.hi[k];
+        cen[3 * (size_t)s + k] = std::isfinite(c) ? c : 0.0f;
+      }
+      order[s] = s;
+    }
+    build_binary();
+    if (bn[0].count > 0) {
+      // one or two triangles in the whole scene: a root whose only child is that leaf
+      const uint32_t leaf = (uint32_t)bn.size();
+      bn.push_back(bn[0]);
+      bn[0].count = 0;
+      bn[0].left = bn[0].right = leaf;
+      wide.clear();
+      wide_of.assign(bn.size(), 0xffffffffu);
+      Wide w;
+      w.n_child = 1;
+      w.child[0] = leaf;
+      wide_of[0] = 0;
+      wide.push_back(w);
+    } else {
+      collapse();
+    }
+    emit();
+  }
+};
+
+}  // namespace
+
+void build_fast_tree(const PtSceneDesc &d, FlatScene &out) {
+  FastBuilder b(d, out);
+  b.run();
+}
+
+}  // namespace ptl

@@ -93,6 +93,7 @@ struct Flattener {
     memset(&r, 0, sizeof(r));
     r.tri_id = 0xffffffffu;
     out.tris.push_back(r);
+    out.tri_gate.push_back(NO_GATE);
     out.tri_levels.push_back(0);
     e.ref = REF_LEAF | next_slot;
     ++next_slot;
@@ -196,7 +197,19 @@ struct Flattener {
     return g;
   }
 
-  void put_triangle(uint32_t mesh, uint32_t local, uint32_t levels) {
+  // Registers the box of an internal node of the reference as a gate and returns its index.
+  uint32_t add_gate(const PtNode &n) {
+    GateBox g;
+    for (int k = 0; k < 3; ++k) {
+      g.lo[k] = n.bmin[k];
+      g.hi[k] = n.bmax[k];
+    }
+    g.pad0 = g.pad1 = 0;
+    out.gates.push_back(g);
+    return (uint32_t)out.gates.size() - 1;
+  }
+
+  void put_triangle(uint32_t mesh, uint32_t local, uint32_t levels, uint32_t gate) {
     const uint32_t gid = d.tri_offset[mesh] + local;
     const float *p = d.tri_verts + (size_t)gid * 9;
     TriRec r;
@@ -211,12 +224,14 @@ struct Flattener {
     r.mat_id = d.mesh_material[mesh];
     r.rank = next_slot;
     out.tris.push_back(r);
+    out.tri_gate.push_back(gate);
     out.tri_levels.push_back((uint8_t)std::min<uint32_t>(levels, 255u));
     ++next_slot;
   }
 
-  // `inner` counts the internal nodes of the reference above this node (HitData::hits, object.cpp:281-282).
-  Entry mesh_node(uint32_t mesh, uint32_t local, uint32_t level, uint32_t inner) {
+  // `inner` counts the internal nodes of the reference above this node (HitData::hits, object.cpp:281-282);
+  // `gate` is the lowest of them (NO_GATE: none).
+  Entry mesh_node(uint32_t mesh, uint32_t local, uint32_t level, uint32_t inner, uint32_t gate) {
     const uint32_t nb = d.blas_node_offset[mesh], ne = d.blas_node_offset[mesh + 1];
     const uint32_t ntri = d.tri_offset[mesh + 1] - d.tri_offset[mesh];
     if (level > kMaxRecursion) return fail("mesh tree deeper than 4096 levels");
@@ -234,13 +249,14 @@ struct Flattener {
         if (local_tri >= ntri) return fail("blas_order entry out of range");
         if (tri_seen[d.tri_offset[mesh] + local_tri]) return fail("triangle referenced twice");
         tri_seen[d.tri_offset[mesh] + local_tri] = 1;
-        put_triangle(mesh, local_tri, inner);
+        put_triangle(mesh, local_tri, inner, gate);
       }
       if (next_slot > MAX_TRI_SLOTS) return fail("more than 2^28 triangles");
       return split_leaf(first_slot, next_slot);
     }
-    Entry l = mesh_node(mesh, n.index_or_first, level + 1, inner + 1);
-    Entry r = mesh_node(mesh, n.index_or_first + 1, level + 1, inner + 1);
+    const uint32_t own = add_gate(n);
+    Entry l = mesh_node(mesh, n.index_or_first, level + 1, inner + 1, own);
+    Entry r = mesh_node(mesh, n.index_or_first + 1, level + 1, inner + 1, own);
     if (failed) return e;
     e.ref = make_node(l, r);
     e.kind = KIND_INTERNAL;
@@ -248,7 +264,7 @@ struct Flattener {
     return e;
   }
 
-  Entry tlas_node(uint32_t i, uint32_t level, uint32_t inner) {
+  Entry tlas_node(uint32_t i, uint32_t level, uint32_t inner, uint32_t gate) {
     if (level > kMaxRecursion) return fail("top-level tree deeper than 4096 levels");
     if (i >= d.n_tlas_nodes) return fail("top-level node index out of range");
     if (tlas_seen[i]) return fail("top-level node referenced twice");
@@ -265,13 +281,14 @@ struct Flattener {
         if (mesh_seen[mesh]) return fail("mesh referenced twice");
         mesh_seen[mesh] = 1;
         if (d.blas_node_offset[mesh + 1] <= d.blas_node_offset[mesh]) return fail("mesh without nodes");
-        es.push_back(mesh_node(mesh, 0, level + 1, inner));
+        es.push_back(mesh_node(mesh, 0, level + 1, inner, gate));
         if (failed) return e;
       }
       return group(es, 0, es.size());
     }
-    Entry l = tlas_node(n.index_or_first, level + 1, inner + 1);
-    Entry r = tlas_node(n.index_or_first + 1, level + 1, inner + 1);
+    const uint32_t own = add_gate(n);
+    Entry l = tlas_node(n.index_or_first, level + 1, inner + 1, own);
+    Entry r = tlas_node(n.index_or_first + 1, level + 1, inner + 1, own);
     if (failed) return e;
     e.ref = make_node(l, r);
     e.kind = KIND_INTERNAL;
@@ -401,7 +418,7 @@ struct Flattener {
       if (v >= 1 && v <= 8) leaf_size = (uint32_t)v;
     }
     out.tris.reserve((size_t)d.n_tris + 1);
-    Entry root = tlas_node(0, 0, 0);
+    Entry root = tlas_node(0, 0, 0, NO_GATE);
     if (failed) return PT_ERR_INVALID;
     if (next_slot != d.n_tris) {
       err = "tree does not reach every triangle";
@@ -475,11 +492,72 @@ struct Flattener {
     }
     build_lights();
     out.n_meshes = d.n_meshes;
+    // the fast traversal's own tree; its boxes are widened by 2^-shift of the largest coordinate
+    int shift = 11;
+    if (const char *e = std::getenv("PT_MARGIN_SHIFT")) {  // tuning knob
+      const int v = std::atoi(e);
+      if (v >= 6 && v <= 24) shift = v;
+    }
+    out.margin_rel = std::ldexp(1.0f, -shift);
+    build_fast_tree(d, out);
     return PT_OK;
   }
 };
 
 }  // namespace
+
+// Invariants of the fast tree: every triangle record is referenced by exactly one leaf, every child box
+// contains (with the margin) the boxes or triangles below it, references stay in range.
+int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) {
+  const uint32_t n_tris = (uint32_t)f.tris4.size();
+  if (f.nodes4.empty() || n_tris == 0 || f.tri_id4.size() != n_tris) {
+    err = "fast tree: empty";
+    return PT_ERR_INVALID;
+  }
+  std::vector<uint8_t> seen(n_tris, 0), node_seen(f.nodes4.size(), 0);
+  struct Item { uint32_t node; float lo[3], hi[3]; };
+  std::vector<Item> todo;
+  Item root;
+  root.node = 0;
+  for (int k = 0; k < 3; ++k) { root.lo[k] = -INFINITY; root.hi[k] = INFINITY; }
+  todo.push_back(root);
+  while (!todo.empty()) {
+    const Item it = todo.back();
+    todo.pop_back();
+    if (it.node >= f.nodes4.size() || node_seen[it.node]) { err = "fast tree: node index out of range or referenced twice"; return PT_ERR_INVALID; }
+    node_seen[it.node] = 1;
+    const Quad4Node &q = f.nodes4[it.node];
+    for (int c = 0; c < 4; ++c) {
+      const float lo[3] = {q.lox[c], q.loy[c], q.loz[c]}, hi[3] = {q.hix[c], q.hiy[c], q.hiz[c]};
+      if (lo[0] > hi[0]) continue;  // unused slot
+      for (int k = 0; k < 3; ++k)
+        if (lo[k] < it.lo[k] - 1e-3f || hi[k] > it.hi[k] + 1e-3f) { err = "fast tree: child box outside its parent's"; return PT_ERR_INVALID; }
+      if (q.ref[c] & REF_LEAF) {
+        const uint32_t first = q.ref[c] & REF_FIRST_MASK, cnt = ((q.ref[c] >> 28) & 7u) + 1u;
+        if (first + cnt > n_tris - 1) { err = "fast tree: leaf range out of range"; return PT_ERR_INVALID; }
+        for (uint32_t t = first; t < first + cnt; ++t) {
+          if (seen[t]) { err = "fast tree: triangle in two leaves"; return PT_ERR_INVALID; }
+          seen[t] = 1;
+          const float *p = d.tri_verts + (size_t)f.tri_id4[t] * 9;
+          for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k)
+              if (p[3 * v + k] < lo[k] || p[3 * v + k] > hi[k]) { err = "fast tree: triangle outside its leaf box"; return PT_ERR_INVALID; }
+          if (f.tris4[t].gate != NO_GATE && f.tris4[t].gate >= f.gates.size()) { err = "fast tree: gate index out of range"; return PT_ERR_INVALID; }
+        }
+      } else {
+        Item ch;
+        ch.node = q.ref[c];
+        for (int k = 0; k < 3; ++k) { ch.lo[k] = lo[k]; ch.hi[k] = hi[k]; }
+        todo.push_back(ch);
+      }
+    }
+  }
+  for (uint32_t t = 0; t + 1 < n_tris; ++t)
+    if (!seen[t]) { err = "fast tree: triangle in no leaf"; return PT_ERR_INVALID; }
+  for (size_t i = 0; i < f.nodes4.size(); ++i)
+    if (!node_seen[i]) { err = "fast tree: unreachable node"; return PT_ERR_INVALID; }
+  return PT_OK;
+}
 
 int flatten_scene(const PtSceneDesc &d, FlatScene &out, std::string &err) {
   out = FlatScene();

@@ -20,10 +20,25 @@ struct FlatScene {
   std::vector<float> tri_uv;         // 6 floats per triangle record (u,v of vt0, vt1, vt2); empty without textures
   std::vector<LightRec> lights;
   std::vector<LightTri> light_tris;
+  // The fast traversal's own tree over the same triangles (see pt_fasttree.cpp)
+  std::vector<Quad4Node> nodes4;     // node 0 is the root
+  std::vector<TriRec4> tris4;        // triangle records in that tree's leaf order, plus the degenerate one at the end
+  std::vector<uint32_t> tri_id4;     // per record of tris4: global triangle id in file order (0xffffffff: the degenerate one)
+  std::vector<GateBox> gates;        // boxes of the reference's internal nodes
+  std::vector<float> tri_uv4;        // texture coordinates in tris4 order; empty without textures
+  std::vector<uint32_t> tri_gate;    // per record of tris: the same gate index (input of the fast-tree builder)
+  uint32_t max_depth4 = 0;           // stack entries the deepest descent of the fast tree can need
+  float margin_rel = 0;              // boxes of the fast tree are widened by margin_rel * max_abs_coord + 2e-5
   uint32_t max_depth = 0;            // stack entries the deepest descent needs
   uint32_t n_meshes = 0;
   float max_abs_coord = 0;           // largest |coordinate| of any vertex
 };
+
+// Builds nodes4 / tris4 / gate4 / tri_uv4 from tris, tri_gate and the description's vertices.
+void build_fast_tree(const PtSceneDesc &d, FlatScene &out);
+
+// Verifies the invariants of the fast tree (used by pt_scene_check).
+int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err);
 
 // Returns PT_OK or a negative PtStatus with `err` filled in.
 int flatten_scene(const PtSceneDesc &d, FlatScene &out, std::string &err);

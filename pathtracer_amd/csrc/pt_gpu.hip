@@ -67,6 +67,7 @@ struct Workspace {
   float *shadow_block = nullptr;             // split shading only: ShadowDev arrays
   ShadowDev sd{};
   size_t shadow_items = 0;                   // capacity in (vertex, light) pairs
+  bool has_shadow = false;                   // laid out with the visibility-ray arrays
 };
 
 // Launch geometry of the traversal kernels for one scene.
@@ -79,6 +80,8 @@ struct Plan {
   bool resident = false;    // all nodes, all triangles and the whole stack are in LDS
   bool split = false;       // shading runs as three kernels (visibility rays walked on their own)
   bool refill_resident = false;  // closest-hit kernel hands out rays lane by lane even when the scene is in LDS
+  uint32_t quorum_any = 32;      // see SceneDev::quorum_any
+  uint32_t *d_spill = nullptr;   // traversal-stack spill area (trees deeper than the LDS part of the stack)
 };
 
 struct PtScene {
@@ -93,11 +96,16 @@ struct PtScene {
   float *d_tri_uv = nullptr;               // textured scenes only
   ptl::TexRec *d_textures = nullptr;
   uint8_t *d_texels = nullptr;
-  uint32_t max_depth = 0, n_meshes = 0;
+  ptl::Quad4Node *d_nodes4 = nullptr;      // the fast mode's own tree
+  ptl::TriRec4 *d_tris4 = nullptr;
+  uint32_t *d_tri_id4 = nullptr;
+  ptl::GateBox *d_gates = nullptr;
+  float *d_tri_uv4 = nullptr;
+  uint32_t max_depth = 0, max_depth4 = 0, n_meshes = 0;
   uint64_t bytes = 0;
-  Plan plan;
+  Plan plan;                               // launches over the reference-shaped tree (exact mode, fast-binary mode)
+  Plan plan4;                              // launches over the fast tree
   Workspace ws;
-  uint32_t *d_spill = nullptr;             // traversal-stack spill area (deep trees only)
   uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, work-queue heads of trace, shade, shade phase 1, visibility walk
   unsigned long long *d_stats = nullptr;   // node boxes, triangle tests: closest [0,1], visibility [2,3]
   uint32_t *h_cnt = nullptr;               // pinned
@@ -167,13 +175,17 @@ static int stack_class(uint32_t depth) {
 
 // 160 KiB of LDS per CU: the per-lane stacks take STACK*4 bytes per thread, the rest
 // holds the top of the tree and, when they fit as well, all triangles.
-static int make_plan(PtScene *s) {
-  Plan &p = s->plan;
-  p.stack = stack_class(s->max_depth);
+static int make_plan(PtScene *s, bool wide) {
+  Plan &p = wide ? s->plan4 : s->plan;
+  const uint32_t depth = wide ? s->max_depth4 : s->max_depth;
+  const uint32_t n_nodes = wide ? s->dev.n_nodes4 : s->dev.n_nodes, n_tris = wide ? s->dev.n_tris4 : s->dev.n_tris;
+  const size_t node_lds = wide ? 7 * 16 : sizeof(ptl::WideNode);  // the fast tree's nodes are kept without their padding piece
+  const size_t gate_bytes = wide ? (size_t)s->dev.n_gates * sizeof(ptl::GateBox) : 0;
+  p.stack = stack_class(depth);
   if (!p.stack) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
   // deeper trees keep only the first entries in LDS and spill the rest to global memory, so
   // that LDS still holds 16 waves per CU and a useful part of the tree
-  int cap = 24;
+  int cap = wide ? 16 : 24;  // a descent of the four-child tree rarely holds more than a dozen entries
   if (const char *e = std::getenv("PT_STACK_CAP")) {  // tuning knob
     const int c = std::atoi(e);
     if (c >= 4 && c <= 128) cap = c;
@@ -187,9 +199,9 @@ static int make_plan(PtScene *s) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
   const size_t lds_cu = 160 * 1024;
-  if (const char *e = std::getenv("PT_STACK")) {  // tuning knob: never below what the tree needs
+  if (const char *e = std::getenv("PT_STACK")) {  // tuning knob: entries per lane kept in LDS
     const int st = std::atoi(e);
-    if (st >= p.stack && st <= 128) p.stack = st;
+    if (st >= 4 && st <= 128 && (size_t)st * p.block * 4 <= 128 * 1024) p.stack = st;
   }
   const size_t stack_bytes = (size_t)p.stack * p.block * 4;
   size_t budget = lds_cu - stack_bytes - 512;
@@ -197,17 +209,20 @@ static int make_plan(PtScene *s) {
     const size_t kb = (size_t)std::atol(e) * 1024;
     if (kb < budget) budget = kb;
   }
-  const size_t node_bytes = (size_t)s->dev.n_nodes * sizeof(ptl::WideNode);
-  const size_t tri_bytes = (size_t)s->dev.n_tris * sizeof(ptl::TriRec);
-  if (node_bytes + tri_bytes <= budget) {
-    p.lds.n_nodes = s->dev.n_nodes;
-    p.lds.n_tris = s->dev.n_tris;
+  const size_t node_bytes = (size_t)n_nodes * node_lds;
+  const size_t tri_bytes = (size_t)n_tris * sizeof(ptl::TriRec);
+  p.lds.n_gates = 0;
+  if (node_bytes + tri_bytes + gate_bytes <= budget) {
+    p.lds.n_nodes = n_nodes;
+    p.lds.n_tris = n_tris;
+    p.lds.n_gates = wide ? s->dev.n_gates : 0;
   } else {
-    const size_t fit = budget / sizeof(ptl::WideNode);
-    p.lds.n_nodes = (uint32_t)(fit < s->dev.n_nodes ? fit : s->dev.n_nodes);
+    const size_t fit = budget / node_lds;
+    p.lds.n_nodes = (uint32_t)(fit < n_nodes ? fit : n_nodes);
     p.lds.n_tris = 0;
   }
-  p.lds_bytes = (size_t)p.lds.n_nodes * sizeof(ptl::WideNode) + (size_t)p.lds.n_tris * sizeof(ptl::TriRec) + stack_bytes;
+  p.lds_bytes = (size_t)p.lds.n_nodes * node_lds + (size_t)p.lds.n_tris * sizeof(ptl::TriRec) +
+                (size_t)p.lds.n_gates * sizeof(ptl::GateBox) + stack_bytes;
   unsigned per_cu = (unsigned)(lds_cu / p.lds_bytes);
   const unsigned by_threads = 2048u / (unsigned)p.block;
   if (per_cu > by_threads) per_cu = by_threads;
@@ -215,21 +230,32 @@ static int make_plan(PtScene *s) {
   p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
   p.lds.stack_lds = (uint32_t)p.stack;
   p.lds.spill = nullptr;
-  p.resident = p.lds.n_nodes == s->dev.n_nodes && p.lds.n_tris == s->dev.n_tris && s->max_depth <= (uint32_t)p.stack &&
-               !std::getenv("PT_NO_RESIDENT");
+  p.resident = p.lds.n_nodes == n_nodes && p.lds.n_tris == n_tris && !std::getenv("PT_NO_RESIDENT");
   p.split = !p.resident;
   if (const char *e = std::getenv("PT_RES_REFILL")) p.refill_resident = std::atoi(e) != 0;  // tuning knob
   if (const char *e = std::getenv("PT_SPLIT")) p.split = std::atoi(e) != 0;  // tuning knob
   if (std::getenv("PT_VERBOSE"))
-    std::fprintf(stderr, "ptgpu plan: depth %u, block %d, LDS stack %d entries/lane, %u nodes + %u triangles in LDS, %zu B LDS per workgroup, %u resident workgroups\n",
-                 s->max_depth, p.block, p.stack, p.lds.n_nodes, p.lds.n_tris, p.lds_bytes, p.max_blocks);
-  if (s->max_depth > (uint32_t)p.stack) {
-    const size_t words = (size_t)p.max_blocks * p.block * (s->max_depth - (uint32_t)p.stack);
-    HIP_TRY(hipMalloc(&s->d_spill, words * sizeof(uint32_t)));
+    std::fprintf(stderr, "ptgpu plan (%s tree): depth %u, block %d, LDS stack %d entries/lane, %u nodes + %u triangles + %u gates in LDS, %zu B LDS per workgroup, %u resident workgroups\n",
+                 wide ? "fast" : "reference-shaped", depth, p.block, p.stack, p.lds.n_nodes, p.lds.n_tris, p.lds.n_gates, p.lds_bytes, p.max_blocks);
+  if (depth > (uint32_t)p.stack) {
+    const size_t words = (size_t)p.max_blocks * p.block * (depth - (uint32_t)p.stack);
+    HIP_TRY(hipMalloc(&p.d_spill, words * sizeof(uint32_t)));
     s->bytes += words * sizeof(uint32_t);
-    p.lds.spill = s->d_spill;
+    p.lds.spill = p.d_spill;
   }
+  // measured: visibility walks outside LDS do best testing parked leaves at a quarter of the
+  // unfinished lanes (terrain with 64 lights -5 %), those in LDS at half
+  p.quorum_any = s->dev.quorum_any;
+  if (!p.resident && !std::getenv("PT_QUORUM_ANY")) p.quorum_any = 16;
   return PT_OK;
+}
+
+// Plan and device view of the scene for a traversal mode.
+static const Plan &plan_of(const PtScene *s, int mode) { return mode_wide(mode) ? s->plan4 : s->plan; }
+static SceneDev dev_of(const PtScene *s, int mode) {
+  SceneDev d = s->dev;
+  d.quorum_any = plan_of(s, mode).quorum_any;
+  return d;
 }
 
 static void free_workspace(Workspace &w) {
@@ -276,6 +302,7 @@ static int carve_workspace(Workspace &w, size_t cap, uint32_t n_lights, bool spl
   w.block_tot = w.chunk_base + n_chunks;
   w.alive = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(w.block_tot + kScanBlock) + 63) & ~(uintptr_t)63);
   w.shadow_items = 0;
+  w.has_shadow = split;
   if (split) {
     const size_t items = stride * n_lights;
     w.sd.vbase = shadow_block;
@@ -289,9 +316,11 @@ static int carve_workspace(Workspace &w, size_t cap, uint32_t n_lights, bool spl
   return PT_OK;
 }
 
-static int ensure_workspace(PtScene *s, size_t cap) {
+static int ensure_workspace(PtScene *s, size_t cap, bool split) {
   Workspace &w = s->ws;
-  if (w.cap >= cap) return PT_OK;
+  if (w.cap >= cap && (w.has_shadow || !split)) return PT_OK;
+  if (w.cap > cap) cap = w.cap;
+  split = split || w.has_shadow;
   free_workspace(w);
   const size_t stride = ws_stride(cap);
   if ((stride / 64 + kScanSpan - 1) / kScanSpan > (size_t)kScanBlock || stride > 0x7fffffffu)
@@ -301,14 +330,14 @@ static int ensure_workspace(PtScene *s, size_t cap) {
     (void)hipGetLastError();
     return fail(PT_ERR_NOMEM, "out of device memory for the path workspace");
   }
-  const size_t sb = ws_shadow_bytes(stride, s->dev.n_lights, s->plan.split);
+  const size_t sb = ws_shadow_bytes(stride, s->dev.n_lights, split);
   if (sb && hipMalloc(&w.shadow_block, sb) != hipSuccess) {
     w.shadow_block = nullptr;
     (void)hipGetLastError();
     free_workspace(w);
     return fail(PT_ERR_NOMEM, "out of device memory for the visibility-ray workspace");
   }
-  return carve_workspace(w, cap, s->dev.n_lights, s->plan.split, w.block, w.shadow_block);
+  return carve_workspace(w, cap, s->dev.n_lights, split, w.block, w.shadow_block);
 }
 
 // Dynamic LDS above 64 KiB has to be allowed per kernel once.
@@ -361,13 +390,15 @@ static int dispatch_plan(const Plan &p, F &&f) {
 
 template <int MODE, bool COUNT>
 static int launch_trace_queue(PtScene *s, const PathFrame &F, int depth, uint32_t n, const QueueDev &q, hipStream_t st) {
-  return dispatch_plan(s->plan, [&](auto BL) -> int {
+  const Plan &P = plan_of(s, MODE);
+  const SceneDev D = dev_of(s, MODE);
+  return dispatch_plan(P, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = !s->plan.resident ? k_trace_queue<MODE, BLOCK, COUNT, false, true>
-             : s->plan.refill_resident ? k_trace_queue<MODE, BLOCK, COUNT, true, true> : k_trace_queue<MODE, BLOCK, COUNT, true, false>;
-    int rc = allow_lds(k, s->plan.lds_bytes);
+    auto k = !P.resident ? k_trace_queue<MODE, BLOCK, COUNT, false, true>
+             : P.refill_resident ? k_trace_queue<MODE, BLOCK, COUNT, true, true> : k_trace_queue<MODE, BLOCK, COUNT, true, false>;
+    int rc = allow_lds(k, P.lds_bytes);
     if (rc != PT_OK) return rc;
-    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), F, depth, n, q,
+    hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, run_length(P, n), F, depth, n, q,
                        s->aw->hit, s->aw->alive, s->acnt + 2, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
@@ -377,17 +408,19 @@ static int launch_trace_queue(PtScene *s, const PathFrame &F, int depth, uint32_
 template <int MODE, bool COUNT>
 static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, const QueueDev &in,
                         const QueueDev &out, hipStream_t st) {
-  return dispatch_plan(s->plan, [&](auto BL) -> int {
+  const Plan &P = plan_of(s, MODE);
+  const SceneDev D = dev_of(s, MODE);
+  return dispatch_plan(P, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
     const Workspace &w = *s->aw;
-    const uint32_t kRun = run_length(s->plan, n);
-    if (!s->plan.split) {
+    const uint32_t kRun = run_length(P, n);
+    if (!P.split) {
       const bool tex = s->dev.n_tex != 0;
-      auto k = s->plan.resident ? (tex ? k_shade<MODE, BLOCK, COUNT, true, 0, true> : k_shade<MODE, BLOCK, COUNT, true, 0, false>)
+      auto k = P.resident ? (tex ? k_shade<MODE, BLOCK, COUNT, true, 0, true> : k_shade<MODE, BLOCK, COUNT, true, 0, false>)
                                 : (tex ? k_shade<MODE, BLOCK, COUNT, false, 0, true> : k_shade<MODE, BLOCK, COUNT, false, 0, false>);
-      int rc = allow_lds(k, s->plan.lds_bytes);
+      int rc = allow_lds(k, P.lds_bytes);
       if (rc != PT_OK) return rc;
-      hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, kRun, F, depth, n, in,
+      hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, kRun, F, depth, n, in,
                          w.hit, out, w.sd, w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
       HIP_TRY(hipGetLastError());
       return PT_OK;
@@ -395,18 +428,18 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
     // prepare the visibility rays, walk them (with per-lane refill when the scene is outside LDS), finish the vertices
     if ((size_t)n * s->dev.n_lights > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
     auto ka = k_shade<MODE, BLOCK, COUNT, false, 1, false>;
-    hipLaunchKernelGGL(ka, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
+    hipLaunchKernelGGL(ka, grid_for(P, n), dim3(BLOCK), 0, st, D, P.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
                        w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
     HIP_TRY(hipGetLastError());
-    auto kw = s->plan.resident ? k_shadow_walk<MODE, BLOCK, COUNT, true> : k_shadow_walk<MODE, BLOCK, COUNT, false>;
-    int rc = allow_lds(kw, s->plan.lds_bytes);
+    auto kw = P.resident ? k_shadow_walk<MODE, BLOCK, COUNT, true> : k_shadow_walk<MODE, BLOCK, COUNT, false>;
+    int rc = allow_lds(kw, P.lds_bytes);
     if (rc != PT_OK) return rc;
     const size_t items = (size_t)n * s->dev.n_lights;
-    hipLaunchKernelGGL(kw, grid_for(s->plan, items), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds,
-                       run_length(s->plan, items), n, w.hit, w.sd, s->acnt + 5, s->d_stats);
+    hipLaunchKernelGGL(kw, grid_for(P, items), dim3(BLOCK), P.lds_bytes, st, D, P.lds,
+                       run_length(P, items), n, w.hit, w.sd, s->acnt + 5, s->d_stats);
     HIP_TRY(hipGetLastError());
     auto kb = s->dev.n_tex != 0 ? k_shade<MODE, BLOCK, COUNT, false, 2, true> : k_shade<MODE, BLOCK, COUNT, false, 2, false>;
-    hipLaunchKernelGGL(kb, grid_for(s->plan, n), dim3(BLOCK), 0, st, s->dev, s->plan.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
+    hipLaunchKernelGGL(kb, grid_for(P, n), dim3(BLOCK), 0, st, D, P.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
                        w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
@@ -418,12 +451,14 @@ static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *
                             const float *dx, const float *dy, const float *dz, float *t, int32_t *tri, float *u,
                             float *v, hipStream_t st) {
   HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
-  return dispatch_plan(s->plan, [&](auto BL) -> int {
+  const Plan &P = plan_of(s, MODE);
+  const SceneDev D = dev_of(s, MODE);
+  return dispatch_plan(P, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = s->plan.resident ? k_trace_api<MODE, BLOCK, COUNT, true> : k_trace_api<MODE, BLOCK, COUNT, false>;
-    int rc = allow_lds(k, s->plan.lds_bytes);
+    auto k = P.resident ? k_trace_api<MODE, BLOCK, COUNT, true> : k_trace_api<MODE, BLOCK, COUNT, false>;
+    int rc = allow_lds(k, P.lds_bytes);
     if (rc != PT_OK) return rc;
-    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
+    hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, run_length(P, n), n, ox, oy, oz,
                        dx, dy, dz, t, tri, u, v, s->acnt + 2, s->d_stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
@@ -434,12 +469,14 @@ template <int MODE>
 static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
                           const float *dy, const float *dz, uint8_t *hit, hipStream_t st) {
   HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
-  return dispatch_plan(s->plan, [&](auto BL) -> int {
+  const Plan &P = plan_of(s, MODE);
+  const SceneDev D = dev_of(s, MODE);
+  return dispatch_plan(P, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = s->plan.resident ? k_any_api<MODE, BLOCK, true> : k_any_api<MODE, BLOCK, false>;
-    int rc = allow_lds(k, s->plan.lds_bytes);
+    auto k = P.resident ? k_any_api<MODE, BLOCK, true> : k_any_api<MODE, BLOCK, false>;
+    int rc = allow_lds(k, P.lds_bytes);
     if (rc != PT_OK) return rc;
-    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
+    hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, run_length(P, n), n, ox, oy, oz,
                        dx, dy, dz, hit, s->acnt + 2);
     HIP_TRY(hipGetLastError());
     return PT_OK;
@@ -450,16 +487,30 @@ template <int MODE>
 static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
                            const float *dy, const float *dz, int32_t *hits, hipStream_t st) {
   HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
-  return dispatch_plan(s->plan, [&](auto BL) -> int {
+  const Plan &P = plan_of(s, MODE);
+  const SceneDev D = dev_of(s, MODE);
+  return dispatch_plan(P, [&](auto BL) -> int {
     constexpr int BLOCK = decltype(BL)::value;
-    auto k = s->plan.resident ? k_hits_api<MODE, BLOCK, true> : k_hits_api<MODE, BLOCK, false>;
-    int rc = allow_lds(k, s->plan.lds_bytes);
+    auto k = P.resident ? k_hits_api<MODE, BLOCK, true> : k_hits_api<MODE, BLOCK, false>;
+    int rc = allow_lds(k, P.lds_bytes);
     if (rc != PT_OK) return rc;
-    hipLaunchKernelGGL(k, grid_for(s->plan, n), dim3(BLOCK), s->plan.lds_bytes, st, s->dev, s->plan.lds, run_length(s->plan, n), n, ox, oy, oz,
+    hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, run_length(P, n), n, ox, oy, oz,
                        dx, dy, dz, s->d_levels, hits, s->acnt + 2);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
+}
+
+// Calls f(M) with the traversal mode as an integral constant.
+static bool valid_mode(int mode) { return mode == PT_TRACE_EXACT || mode == PT_TRACE_FAST || mode == PT_TRACE_FAST_BINARY; }
+template <typename F>
+static int with_mode(int mode, F &&f) {
+  switch (mode) {
+    case PT_TRACE_EXACT: return f(std::integral_constant<int, PT_TRACE_EXACT>{});
+    case PT_TRACE_FAST: return f(std::integral_constant<int, PT_TRACE_FAST>{});
+    case PT_TRACE_FAST_BINARY: return f(std::integral_constant<int, PT_TRACE_FAST_BINARY>{});
+    default: return fail(PT_ERR_INVALID, "unknown trace mode");
+  }
 }
 
 static PathFrame path_frame(const FrameDev &F) {
@@ -553,7 +604,13 @@ void pt_scene_free(PtScene *s) {
   if (s->d_tri_uv) (void)hipFree(s->d_tri_uv);
   if (s->d_textures) (void)hipFree(s->d_textures);
   if (s->d_texels) (void)hipFree(s->d_texels);
-  if (s->d_spill) (void)hipFree(s->d_spill);
+  if (s->plan.d_spill) (void)hipFree(s->plan.d_spill);
+  if (s->plan4.d_spill) (void)hipFree(s->plan4.d_spill);
+  if (s->d_nodes4) (void)hipFree(s->d_nodes4);
+  if (s->d_tris4) (void)hipFree(s->d_tris4);
+  if (s->d_tri_id4) (void)hipFree(s->d_tri_id4);
+  if (s->d_gates) (void)hipFree(s->d_gates);
+  if (s->d_tri_uv4) (void)hipFree(s->d_tri_uv4);
   if (s->d_cnt) (void)hipFree(s->d_cnt);
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->h_cnt) (void)hipHostFree(s->h_cnt);
@@ -580,7 +637,12 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(up(&s->d_lights, f.lights));
   HIP_TRY(up(&s->d_ltris, f.light_tris));
   HIP_TRY(up(&s->d_levels, f.tri_levels));
+  HIP_TRY(up(&s->d_nodes4, f.nodes4));
+  HIP_TRY(up(&s->d_tris4, f.tris4));
+  HIP_TRY(up(&s->d_tri_id4, f.tri_id4));
+  HIP_TRY(up(&s->d_gates, f.gates));
   if (!f.textures.empty()) {
+    HIP_TRY(up(&s->d_tri_uv4, f.tri_uv4));
     HIP_TRY(up(&s->d_tri_uv, f.tri_uv));
     HIP_TRY(up(&s->d_textures, f.textures));
     HIP_TRY(up(&s->d_texels, f.texels));
@@ -603,6 +665,9 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.lights = s->d_lights; s->dev.light_tris = s->d_ltris;
   s->dev.n_nodes = (uint32_t)f.nodes.size(); s->dev.n_tris = (uint32_t)f.tris.size();
   s->dev.n_lights = (uint32_t)f.lights.size(); s->dev.n_mats = (uint32_t)f.mats.size();
+  s->dev.nodes4 = s->d_nodes4; s->dev.tris4 = s->d_tris4; s->dev.tri_id4 = s->d_tri_id4; s->dev.gates = s->d_gates;
+  s->dev.tri_uv4 = s->d_tri_uv4;
+  s->dev.n_nodes4 = (uint32_t)f.nodes4.size(); s->dev.n_tris4 = (uint32_t)f.tris4.size(); s->dev.n_gates = (uint32_t)f.gates.size();
   s->dev.margin = f.max_abs_coord * (1.0f / 2048.0f) + 2.0e-5f;
   s->dev.quorum = 32;
   s->dev.quorum_any = 32;
@@ -619,11 +684,9 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     const int q = std::atoi(e);
     if (q >= 1 && q <= 64) s->dev.quorum = (uint32_t)q;
   }
-  s->max_depth = f.max_depth; s->n_meshes = f.n_meshes;
-  const int rc = make_plan(s);
-  // measured: visibility walks outside LDS do best testing parked leaves at a quarter of the
-  // unfinished lanes (terrain with 64 lights -5 %), those in LDS at half
-  if (rc == PT_OK && !s->plan.resident && !std::getenv("PT_QUORUM_ANY")) s->dev.quorum_any = 16;
+  s->max_depth = f.max_depth; s->max_depth4 = f.max_depth4; s->n_meshes = f.n_meshes;
+  int rc = make_plan(s, false);
+  if (rc == PT_OK) rc = make_plan(s, true);
   return rc;
 }
 
@@ -642,7 +705,7 @@ int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out) {
     return fail(PT_ERR_NOMEM, "out of host memory while flattening the scene");
   }
   if (rc != PT_OK) return fail(rc, err);
-  if (stack_class(flat.max_depth) == 0) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
+  if (stack_class(flat.max_depth) == 0 || stack_class(flat.max_depth4) == 0) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
   PtScene *s = new (std::nothrow) PtScene();
   if (!s) return fail(PT_ERR_NOMEM, "out of host memory");
   s->device = device;
@@ -657,12 +720,37 @@ int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out) {
   return PT_OK;
 }
 
+int pt_scene_check(const PtSceneDesc *desc, PtSceneInfo *info) {
+  if (!desc) return fail(PT_ERR_INVALID, "null argument");
+  ptl::FlatScene flat;
+  std::string err;
+  int rc;
+  try {
+    rc = ptl::flatten_scene(*desc, flat, err);
+    if (rc == PT_OK) rc = ptl::check_fast_tree(*desc, flat, err);
+  } catch (const std::bad_alloc &) {
+    return fail(PT_ERR_NOMEM, "out of host memory while flattening the scene");
+  }
+  if (rc != PT_OK) return fail(rc, err);
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    info->n_meshes = flat.n_meshes;
+    info->n_tris = (uint32_t)flat.tris.size() - 1;
+    info->n_lights = (uint32_t)flat.lights.size();
+    info->n_wide_nodes = (uint32_t)flat.nodes.size(); info->max_depth = flat.max_depth;
+    info->n_fast_nodes = (uint32_t)flat.nodes4.size(); info->fast_max_depth = flat.max_depth4;
+    info->n_gates = (uint32_t)flat.gates.size();
+  }
+  return PT_OK;
+}
+
 int pt_scene_info(const PtScene *s, PtSceneInfo *info) {
   if (!s || !info) return fail(PT_ERR_INVALID, "null argument");
   info->n_meshes = s->n_meshes;
   info->n_tris = s->dev.n_tris - 1;  // without the degenerate filler
   info->n_lights = s->dev.n_lights;
   info->n_wide_nodes = s->dev.n_nodes; info->max_depth = s->max_depth; info->device = (uint32_t)s->device;
+  info->n_fast_nodes = s->dev.n_nodes4; info->fast_max_depth = s->max_depth4; info->n_gates = s->dev.n_gates;
   info->device_bytes = s->bytes;
   return PT_OK;
 }
@@ -680,15 +768,14 @@ static int trace_dev(PtScene *s, size_t n, const float *ox, const float *oy, con
                      hipStream_t st) {
   if (n == 0) return PT_OK;
   if (n > ((size_t)1 << 36)) return fail(PT_ERR_INVALID, "too many rays for one call");  // the work-queue head counts chunks of 64 in 32 bits
-  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   int rc = enter_stream(s, st);
   if (rc != PT_OK) return rc;
-  if (mode == PT_TRACE_EXACT)
-    rc = s->count_stats ? launch_trace_api<PT_TRACE_EXACT, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
-                        : launch_trace_api<PT_TRACE_EXACT, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
-  else
-    rc = s->count_stats ? launch_trace_api<PT_TRACE_FAST, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
-                        : launch_trace_api<PT_TRACE_FAST, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
+  rc = with_mode(mode, [&](auto MM) -> int {
+    constexpr int M = decltype(MM)::value;
+    return s->count_stats ? launch_trace_api<M, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
+                          : launch_trace_api<M, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
+  });
   if (rc != PT_OK) return rc;
   return leave_stream(s, st);
 }
@@ -746,7 +833,7 @@ int pt_trace_closest(PtScene *s, size_t n, const float *ox, const float *oy, con
                      const float *dy, const float *dz, float *t, int32_t *tri, float *u, float *v, int mode) {
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !t || !tri)) return fail(PT_ERR_INVALID, "null ray or result array");
-  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
@@ -779,7 +866,7 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
                  const float *dy, const float *dz, uint8_t *hit, int mode) {
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hit)) return fail(PT_ERR_INVALID, "null ray or result array");
-  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
@@ -797,8 +884,9 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
     for (int a = 0; a < 6 && e == hipSuccess; ++a) e = hipMemcpy(buf + a * m, src[a], k * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
     uint8_t *dh = reinterpret_cast<uint8_t *>(buf + 6 * m);
-    rc = mode == PT_TRACE_EXACT ? launch_any_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0)
-                                : launch_any_api<PT_TRACE_FAST>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
+    rc = with_mode(mode, [&](auto MM) -> int {
+      return launch_any_api<decltype(MM)::value>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
+    });
     if (rc != PT_OK) break;
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(hit + off, dh, k, hipMemcpyDeviceToHost);
@@ -812,7 +900,7 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
                   const float *dy, const float *dz, int32_t *hits, int mode) {
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hits)) return fail(PT_ERR_INVALID, "null ray or result array");
-  if (mode != PT_TRACE_EXACT && mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
@@ -830,8 +918,9 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
     for (int a = 0; a < 6 && e == hipSuccess; ++a) e = hipMemcpy(buf + a * m, src[a], k * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
     int32_t *dh = reinterpret_cast<int32_t *>(buf + 6 * m);
+    // HitData::hits is a property of the reference's trees: both pruning modes walk those
     rc = mode == PT_TRACE_EXACT ? launch_hits_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0)
-                                : launch_hits_api<PT_TRACE_FAST>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
+                                : launch_hits_api<PT_TRACE_FAST_BINARY>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
     if (rc != PT_OK) break;
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(hits + off, dh, k * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -867,7 +956,7 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
   int rc = PT_OK;
   Workspace &w = *s->aw;
   uint32_t *cnt = s->acnt;
-  const bool exact = o.trace_mode == PT_TRACE_EXACT, cs = s->count_stats;
+  const bool cs = s->count_stats;
   const bool prof = s->profile;
   auto elapsed = [&](int a, int b, double &acc) -> int {
     float ms = 0;
@@ -894,16 +983,20 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
       HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), st));
       if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
-      if (exact) rc = cs ? launch_trace_queue<PT_TRACE_EXACT, true>(s, PF, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_EXACT, false>(s, PF, depth, n, w.q[cur], st);
-      else rc = cs ? launch_trace_queue<PT_TRACE_FAST, true>(s, PF, depth, n, w.q[cur], st) : launch_trace_queue<PT_TRACE_FAST, false>(s, PF, depth, n, w.q[cur], st);
+      rc = with_mode(o.trace_mode, [&](auto MM) -> int {
+        constexpr int M = decltype(MM)::value;
+        return cs ? launch_trace_queue<M, true>(s, PF, depth, n, w.q[cur], st) : launch_trace_queue<M, false>(s, PF, depth, n, w.q[cur], st);
+      });
       if (rc != PT_OK) return rc;
       const uint32_t n_chunks = (n + 63) / 64, n_sblocks = (n_chunks + kScanSpan - 1) / kScanSpan;
       hipLaunchKernelGGL(k_scan_local, dim3(n_sblocks), dim3(kScanBlock), 0, st, n, n_chunks, w.alive, w.chunk_mask, w.chunk_base, w.block_tot);
       hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, n_sblocks, w.block_tot, cnt);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
-      if (exact) rc = cs ? launch_shade<PT_TRACE_EXACT, true>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_EXACT, false>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st);
-      else rc = cs ? launch_shade<PT_TRACE_FAST, true>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<PT_TRACE_FAST, false>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st);
+      rc = with_mode(o.trace_mode, [&](auto MM) -> int {
+        constexpr int M = decltype(MM)::value;
+        return cs ? launch_shade<M, true>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st) : launch_shade<M, false>(s, PF, depth, n, w.q[cur], w.q[cur ^ 1], st);
+      });
       if (rc != PT_OK) return rc;
       if (prof) HIP_TRY(hipEventRecord(s->ev[2], st));
       HIP_TRY(hipMemcpyAsync(s->h_cnt, cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -941,8 +1034,8 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
 }
 
 // Workspace bytes per path in flight for this scene (both parts).
-static uint64_t bytes_per_path(const PtScene *s) {
-  return (uint64_t)(kWsArrays * sizeof(float)) + 2 + (s->plan.split ? 12ull + 25ull * s->dev.n_lights : 0ull);
+static uint64_t bytes_per_path(const PtScene *s, bool split) {
+  return (uint64_t)(kWsArrays * sizeof(float)) + 2 + (split ? 12ull + 25ull * s->dev.n_lights : 0ull);
 }
 
 static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
@@ -953,14 +1046,15 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
   if (rc != PT_OK) return rc;
   PtOptions o;
   if (opt) o = *opt; else pt_options_default(&o);
-  if (o.trace_mode != PT_TRACE_EXACT && o.trace_mode != PT_TRACE_FAST) return fail(PT_ERR_INVALID, "unknown trace mode");
+  if (!valid_mode(o.trace_mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
+  const bool split = plan_of(s, o.trace_mode).split;
   PtCounters c;
   memset(&c, 0, sizeof(c));
   if (spp_count == 0) {
     if (counters) *counters = c;
     return PT_OK;
   }
-  const uint64_t per_path = bytes_per_path(s);
+  const uint64_t per_path = bytes_per_path(s, split);
   uint32_t batch = o.batch_spp;
   Workspace static_ws;
   if (use_static) {
@@ -971,7 +1065,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
     uint64_t cap = room / (per_path + 1);
     cap &= ~63ull;
     // ws_*_bytes round up in places: shrink until the two parts fit
-    while (cap >= 64 && ws_main_bytes(cap) + 256 + ws_shadow_bytes(cap, s->dev.n_lights, s->plan.split) > room) cap -= 64;
+    while (cap >= 64 && ws_main_bytes(cap) + 256 + ws_shadow_bytes(cap, s->dev.n_lights, split) > room) cap -= 64;
     if (cap < F.P) {
       char msg[256];
       std::snprintf(msg, sizeof(msg), "pt_render_dev_static: a %dx%d frame of this scene needs %llu bytes of workspace per sample "
@@ -985,7 +1079,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
     const size_t stride = ws_stride((size_t)batch * F.P);
     float *main_block = reinterpret_cast<float *>(base + 256);
     float *shadow_block = reinterpret_cast<float *>(base + 256 + ((ws_main_bytes(stride) + 255) & ~(size_t)255));
-    rc = carve_workspace(static_ws, (size_t)batch * F.P, s->dev.n_lights, s->plan.split, main_block, shadow_block);
+    rc = carve_workspace(static_ws, (size_t)batch * F.P, s->dev.n_lights, split, main_block, shadow_block);
     if (rc != PT_OK) return rc;
     s->aw = &static_ws;
     s->acnt = reinterpret_cast<uint32_t *>(base);
@@ -998,7 +1092,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
       uint64_t target = 192ull << 20;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const uint64_t have = s->ws.cap ? ws_main_bytes(ws_stride(s->ws.cap)) + ws_shadow_bytes(ws_stride(s->ws.cap), s->dev.n_lights, s->plan.split) : 0;
+        const uint64_t have = s->ws.cap ? ws_main_bytes(ws_stride(s->ws.cap)) + ws_shadow_bytes(ws_stride(s->ws.cap), s->dev.n_lights, s->ws.has_shadow) : 0;
         const uint64_t fit = ((uint64_t)free_b / 4 + have) / per_path;
         if (fit < target) target = fit;
       }
@@ -1010,7 +1104,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
     while ((uint64_t)batch * F.P > (1ull << 31) && batch > 1) batch >>= 1;
     // a failed allocation is retried with half the batch
     for (;;) {
-      rc = ensure_workspace(s, (size_t)batch * F.P);
+      rc = ensure_workspace(s, (size_t)batch * F.P, split);
       if (rc != PT_ERR_NOMEM || batch == 1) break;
       batch = (batch + 1) / 2;
     }

@@ -104,6 +104,7 @@ struct FrameDev {
 struct LdsPlan {
   uint32_t n_nodes;    // top nodes staged in LDS
   uint32_t n_tris;     // 0, or all triangles
+  uint32_t n_gates;    // 0, or all gate boxes (fast tree only)
   uint32_t stack_lds;  // stack entries per lane kept in LDS
   uint32_t *spill;     // global spill area for deeper stacks (null when none is needed)
 };
@@ -186,23 +187,36 @@ __device__ __forceinline__ void wave_add64(unsigned long long *dst, uint32_t v) 
 // third k of triangle i at tris[k*n_tris + i]).  A wave's 64 lanes then read 16-byte pieces
 // whose bank depends on i mod 16; with whole 64-byte records side by side only 4 of the 16
 // bank groups would ever be hit by one instruction.
-template <int BLOCK>
+// The fast tree's nodes are staged as 7 pieces (6 plane pieces + the references), its gate boxes as 2.
+template <int BLOCK, int MODE>
 __device__ __forceinline__ LdsScene stage_scene(const SceneDev &S, LdsPlan plan, uint32_t &stack_base) {
-  const float4 *gn = reinterpret_cast<const float4 *>(S.nodes);
-  const float4 *gt = reinterpret_cast<const float4 *>(S.tris);
+  constexpr bool WIDE = mode_wide(MODE);
+  constexpr uint32_t NP = WIDE ? 7u : 4u;   // node pieces kept in LDS
+  constexpr uint32_t NG = WIDE ? 8u : 4u;   // float4 per node in global memory
+  const float4 *gn = WIDE ? reinterpret_cast<const float4 *>(S.nodes4) : reinterpret_cast<const float4 *>(S.nodes);
+  const float4 *gt = WIDE ? reinterpret_cast<const float4 *>(S.tris4) : reinterpret_cast<const float4 *>(S.tris);
   LdsScene C;
   C.node_base = 0;
-  C.tri_base = 4u * plan.n_nodes;
+  C.tri_base = NP * plan.n_nodes;
+  C.gate_base = C.tri_base + 3u * plan.n_tris;
   C.n_nodes = plan.n_nodes;
   C.n_tris = plan.n_tris;
+  C.n_gates = WIDE ? plan.n_gates : 0u;
   C.stack_lds = plan.stack_lds;
   C.spill_stride = gridDim.x * BLOCK;
   C.spill = plan.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  for (uint32_t i = threadIdx.x; i < 4u * plan.n_nodes; i += BLOCK) pt_smem[(i & 3u) * plan.n_nodes + (i >> 2)] = gn[i];
+  for (uint32_t i = threadIdx.x; i < NG * plan.n_nodes; i += BLOCK) {
+    const uint32_t piece = i % NG, node = i / NG;
+    if (piece < NP) pt_smem[piece * plan.n_nodes + node] = gn[i];
+  }
   for (uint32_t i = threadIdx.x; i < 3u * plan.n_tris; i += BLOCK)
     pt_smem[C.tri_base + (i % 3u) * plan.n_tris + (i / 3u)] = gt[i];
+  if (WIDE) {
+    const float4 *gg = reinterpret_cast<const float4 *>(S.gates);
+    for (uint32_t i = threadIdx.x; i < 2u * C.n_gates; i += BLOCK) pt_smem[C.gate_base + (i & 1u) * C.n_gates + (i >> 1)] = gg[i];
+  }
   __syncthreads();
-  stack_base = 4u * (C.tri_base + 3u * plan.n_tris) + threadIdx.x;  // in 32-bit words
+  stack_base = 4u * (C.gate_base + 2u * C.n_gates) + threadIdx.x;  // in 32-bit words
   return C;
 }
 
@@ -245,7 +259,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
         V3 o, d;
         if (i < n && fetch(i, o, d)) {
           RayState st;
-          walk_init<MODE, WANT_N>(S, st, o, d);
+          walk_init<MODE, WANT_N>(S, C, st, o, d);
           do {
             walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, S.quorum);
           } while (__ballot(!st.done()) != 0);
@@ -288,7 +302,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
           const uint64_t i = pool + rank;
           V3 o, d;
           if (i < pool_end && fetch(i, o, d)) {
-            walk_init<MODE, WANT_N>(S, st, o, d);
+            walk_init<MODE, WANT_N>(S, C, st, o, d);
             mine = i;
             busy = true;
           }
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
                                                        uint32_t n, QueueDev q, HitDev hit, uint8_t *alive_out,
                                                        uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
-  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
   walk_items<MODE, false, COUNT, true, RES, REFILL, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, u
                                                      const float *dy, const float *dz, float *t, int32_t *tri,
                                                      float *u, float *v, uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
-  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
   walk_items<MODE, false, COUNT, false, RES, !RES, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, u
       [&](uint64_t i, const RayState &st) {
         const HitRec &h = st.best;
         t[i] = h.t;
-        tri[i] = h.slot != 0xffffffffu ? (int32_t)S.tris[h.slot].tri_id : -1;
+        tri[i] = h.slot != 0xffffffffu ? (int32_t)(mode_wide(MODE) ? S.tri_id4[h.slot] : S.tris[h.slot].tri_id) : -1;
         if (u) u[i] = h.u;
         if (v) v[i] = h.v;
       });
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uin
                                                    const float *oy, const float *oz, const float *dx, const float *dy,
                                                    const float *dz, uint8_t *hit, uint32_t *head) {
   uint32_t stk;
-  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
   walk_items<MODE, true, false, false, RES, !RES, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, ui
                                                     const float *dz, const uint8_t *levels, int32_t *hits,
                                                     uint32_t *head) {
   uint32_t stk;
-  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
   walk_items<MODE, false, false, false, RES, !RES, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
@@ -485,7 +499,7 @@ template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_shadow_walk(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, HitDev hit,
                                                        ShadowDev sd, uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
-  const LdsScene C = stage_scene<BLOCK>(S, plan, stk);
+  const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
   walk_items<MODE, true, COUNT, false, RES, !RES, BLOCK>(
       S, C, stk, (uint64_t)n * S.n_lights, kRun, head, nb, nt,
@@ -536,8 +550,8 @@ __device__ __forceinline__ int cvt_int_x86(float f) {
 // brdf of a vertex on a textured triangle, camera.cpp:124-146: texture coordinates interpolated
 // with alpha = 1-u-v on vt0, beta = u on vt1, gamma = v on vt2 (HitData::barycentric is
 // (u, v, 1-u-v), object.cpp:428), nearest texel, no flip, the texel itself (no 1/pi).
-__device__ __forceinline__ V3 texel_brdf(const SceneDev &S, uint32_t tex, uint32_t slot, float bu, float bv) {
-  const float *uv = S.tri_uv + (size_t)slot * 6;
+__device__ __forceinline__ V3 texel_brdf(const SceneDev &S, bool wide, uint32_t tex, uint32_t slot, float bu, float bv) {
+  const float *uv = (wide ? S.tri_uv4 : S.tri_uv) + (size_t)slot * 6;  // `slot` is a record of the tree that was walked
   const float beta = bu, gamma = bv, alpha = 1 - bu - bv;
   const float tu = alpha * uv[0] + beta * uv[2] + gamma * uv[4];
   const float tv = alpha * uv[1] + beta * uv[3] + gamma * uv[5];
@@ -607,7 +621,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
                                                  unsigned long long *stats) {
   uint32_t stk = 0;
   LdsScene C{};
-  if constexpr (PHASE == 0) C = stage_scene<BLOCK>(S, plan, stk);
+  if constexpr (PHASE == 0) C = stage_scene<BLOCK, MODE>(S, plan, stk);
   const int lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0, n_hit = 0;
   uint32_t *head = cnt + (PHASE == 1 ? 4 : 3);
@@ -687,7 +701,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
             const uint32_t tex = __float_as_uint(m0.w);
             const bool textured = TEX && tex != 0;                                // camera.cpp:121
             V3 texel = mk(0, 0, 0);
-            if (textured) texel = texel_brdf(S, tex, hit.slot()[i], hit.u()[i], hit.v()[i]);
+            if (textured) texel = texel_brdf(S, mode_wide(MODE), tex, hit.slot()[i], hit.u()[i], hit.v()[i]);
             if (F.sampling == PT_SAMPLE_COSINE) {
               w = cosine_dir(nrm, rx, ry);
               T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob_f);

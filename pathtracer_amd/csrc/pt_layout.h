@@ -42,6 +42,30 @@ struct alignas(16) WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
+// Four-child node of the fast traversal's own tree (128 bytes, one cache line), planes grouped so that a
+// ray reads its near and far planes directly (which of lo / hi is near depends only on the sign of the
+// ray direction on that axis, so a lane addresses piece 2*axis + sign instead of selecting afterwards).
+// As eight float4 "pieces": 0 lo.x[4], 1 hi.x[4], 2 lo.y[4], 3 hi.y[4], 4 lo.z[4], 5 hi.z[4], 6 ref[4], 7 unused.
+// An unused child slot has an inverted box (lo = +inf, hi = -inf) that no ray enters.
+struct alignas(16) Quad4Node {
+  float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];
+  uint32_t ref[4];
+  uint32_t pad[4];
+};
+static_assert(sizeof(Quad4Node) == 128, "Quad4Node must be 128 bytes");
+
+// Box of an internal node of the reference's trees, exactly as given (BVH::Node::box, object.cpp:228-238).
+// The fast traversal accepts a triangle hit only if the ray passes the box of the lowest internal node
+// above that triangle's leaf ("gate"), tested with AABB::intersect's own arithmetic (object.cpp:179-195).
+struct alignas(16) GateBox {
+  float lo[3];
+  float pad0;
+  float hi[3];
+  float pad1;
+};
+static_assert(sizeof(GateBox) == 32, "GateBox must be 32 bytes");
+static const uint32_t NO_GATE = 0xffffffffu;
+
 // 48-byte triangle: v0 and the two edges the reference recomputes per test
 // (e1 = v1 - v0, e2 = v2 - v0, object.cpp:408-409; the subtraction gives the same
 // bits wherever it runs).  Slots are ordered so that a larger slot wins a tie in t.
@@ -54,6 +78,18 @@ struct alignas(16) TriRec {
   uint32_t rank;     // position in the reference's tie order: of two hits at equal t the larger rank wins
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// Triangle record of the fast tree: the same 48 bytes with the gate index where TriRec keeps the
+// triangle id (that one is looked up in a side table when a ray is retired).
+struct alignas(16) TriRec4 {
+  float v0[3];
+  float e1[3];
+  float e2[3];
+  uint32_t gate;     // index into the gate boxes, or NO_GATE
+  uint32_t mat_id;
+  uint32_t rank;
+};
+static_assert(sizeof(TriRec4) == 48, "TriRec4 must be 48 bytes");
 
 struct alignas(16) MatRec {  // Material::diffuse / emission / diffuse_map, object.cpp:146-149
   float kd[3];
