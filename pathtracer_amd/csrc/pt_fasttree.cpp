@@ -240,8 +240,44 @@ struct FastBuilder {
     }
   }
 
-  void emit() {
+  // Boxes the kernels test: a leaf's exact bounds widened by the margin and then clipped to the bounds of its
+  // triangles' gate boxes (a ray that misses the gate cannot produce an accepted hit, and the clipped planes
+  // are the reference's own, tested with the reference's arithmetic: a flat wall keeps its flat box and a ray
+  // leaving that wall does not enter it); an inner node's box is the union of its children's.
+  std::vector<Box3> tb;
+  void test_boxes() {
     const float margin = out.margin_rel * out.max_abs_coord + 2.0e-5f;
+    tb.resize(bn.size());
+    for (size_t i = bn.size(); i-- > 0;) {  // children were created after their parent
+      const BinNode &b = bn[i];
+      if (b.count == 0) {
+        tb[i] = tb[b.left];
+        tb[i].grow(tb[b.right]);
+        continue;
+      }
+      Box3 w = b.box;
+      for (int k = 0; k < 3; ++k) { w.lo[k] -= margin; w.hi[k] += margin; }
+      Box3 g;
+      g.clear();
+      bool all = true;
+      for (uint32_t t = 0; t < b.count; ++t) {
+        const uint32_t gate = out.tri_gate[order[b.first + t]];
+        if (gate == NO_GATE) { all = false; break; }
+        Box3 gb;
+        for (int k = 0; k < 3; ++k) { gb.lo[k] = out.gates[gate].lo[k]; gb.hi[k] = out.gates[gate].hi[k]; }
+        g.grow(gb);
+      }
+      if (all)
+        for (int k = 0; k < 3; ++k) {
+          if (g.lo[k] > w.lo[k]) w.lo[k] = g.lo[k];   // NaN planes leave the widened box alone
+          if (g.hi[k] < w.hi[k]) w.hi[k] = g.hi[k];
+        }
+      tb[i] = w;
+    }
+  }
+
+  void emit() {
+    test_boxes();
     // order of the wide nodes: the top of the tree breadth-first (those are the ones kept in LDS), the
     // rest depth-first
     const uint32_t kTop = 1280;
@@ -321,9 +357,10 @@ struct FastBuilder {
           continue;
         }
         const BinNode &c = bn[w.child[k]];
-        o.lox[k] = c.box.lo[0] - margin; o.hix[k] = c.box.hi[0] + margin;
-        o.loy[k] = c.box.lo[1] - margin; o.hiy[k] = c.box.hi[1] + margin;
-        o.loz[k] = c.box.lo[2] - margin; o.hiz[k] = c.box.hi[2] + margin;
+        const Box3 &cb = tb[w.child[k]];
+        o.lox[k] = cb.lo[0]; o.hix[k] = cb.hi[0];
+        o.loy[k] = cb.lo[1]; o.hiy[k] = cb.hi[1];
+        o.loz[k] = cb.lo[2]; o.hiz[k] = cb.hi[2];
         if (c.count > 0) o.ref[k] = REF_LEAF | ((c.count - 1) << 28) | leaf_first[w.child[k]];
         else o.ref[k] = newidx[wide_of[w.child[k]]];
       }

