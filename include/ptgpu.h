@@ -156,7 +156,7 @@ typedef struct PtCounters {
   uint64_t rays_shadow;   /* visibility queries, camera.cpp:101 */
   uint64_t node_boxes;    /* 32-byte node boxes tested by closest-hit queries (0 unless counting is on) */
   uint64_t tri_tests;     /* triangles tested by closest-hit queries (same) */
-  uint64_t bounce_passes; /* kernel passes over the path queue */
+  uint64_t bounce_passes; /* depth levels processed (passes over the path queue + the levels the tail kernel adds), summed over batches */
   uint64_t shadow_node_boxes; /* node boxes tested by visibility queries (0 unless counting is on) */
   uint64_t shadow_tri_tests;  /* triangles tested by visibility queries (same) */
 } PtCounters;
@@ -169,6 +169,8 @@ typedef struct PtProfile {
   double other_ms;        /* ray generation + resolve */
   uint64_t trace_launches;
   uint64_t shade_launches;
+  double tail_ms;         /* the kernel that follows the last paths of a batch to their ends */
+  uint64_t tail_launches;
 } PtProfile;
 
 const char *pt_last_error(void);

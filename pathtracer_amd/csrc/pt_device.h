@@ -374,10 +374,10 @@ __device__ __forceinline__ bool gate_pass(const SceneDev &S, const LdsScene &C, 
 
 // A triangle hit of a closest-hit walk: it replaces the best one when its t is smaller, or equal with a
 // larger rank (the reference's leftmost-in-leaf / right-sibling rule); in the fast tree only if the ray
-// also passes the triangle's gate.  a, b, c are the three float4 of the triangle's record.
+// also passes the triangle's gate.  c is the third float4 of the triangle's record (gate, material, rank).
 template <int MODE, bool COUNT, bool WANT_N, bool RES>
 __device__ __forceinline__ void consider_hit(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t &n_boxes, bool hit,
-                                             float t, float u, float v, uint32_t slot, float4 a, float4 b, float4 c) {
+                                             float t, uint32_t slot, float4 c) {
   const uint32_t rank = __float_as_uint(c.w);
   bool wins = hit && (t < st.best.t || (t == st.best.t && (int32_t)rank > (int32_t)st.best.rank));
   if (mode_wide(MODE)) {
@@ -390,12 +390,38 @@ __device__ __forceinline__ void consider_hit(const SceneDev &S, const LdsScene &
     st.best.t = t;
     st.best.slot = slot;
     st.best.rank = rank;
-    st.best.u = u;
-    st.best.v = v;
-    if (WANT_N) {
-      st.best.n = cross(mk(a.w, b.x, b.y), mk(b.z, b.w, c.x));  // (v1-v0) x (v2-v0), object.cpp:393
-      st.best.mat = __float_as_uint(c.z);
-    }
+  }
+}
+
+// What a caller wants to know about the closest hit besides t and the triangle: the barycentrics,
+// Triangle::normal() (un-normalised, object.cpp:393) and the material id.  The walk itself carries only t,
+// slot and rank; these come from the winner's record once the walk is over (u and v by the scalar form of
+// the same test: the same operations in the same order, so the same bits as the packed form gave).
+template <int MODE, bool RES>
+__device__ __forceinline__ void hit_finish(const SceneDev &S, const LdsScene &C, V3 o, V3 d, HitRec &h, bool want_uv, bool want_n) {
+  h.u = 0.0f;
+  h.v = 0.0f;
+  h.n = mk(0.0f, 0.0f, 0.0f);
+  h.mat = 0u;
+  if (h.slot == 0xffffffffu) return;
+  float4 a, b, c;
+  if (RES || h.slot < C.n_tris) {
+    const uint32_t at = C.tri_base + h.slot;
+    a = lds_f4(at); b = lds_f4(at + C.n_tris); c = lds_f4(at + 2u * C.n_tris);
+  } else {
+    const void *gtris = mode_wide(MODE) ? (const void *)S.tris4 : (const void *)S.tris;
+    const size_t at = 3u * (size_t)h.slot;
+    a = glb_f4(gtris, at); b = glb_f4(gtris, at + 1); c = glb_f4(gtris, at + 2);
+  }
+  if (want_uv) {
+    float t, u = 0.0f, v = 0.0f;
+    (void)tri_test(a, b, c, o, d, t, u, v);
+    h.u = u;
+    h.v = v;
+  }
+  if (want_n) {
+    h.n = cross(mk(a.w, b.x, b.y), mk(b.z, b.w, c.x));  // (v1-v0) x (v2-v0)
+    h.mat = __float_as_uint(c.z);
   }
 }
 
@@ -571,8 +597,8 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
             break;
           }
         } else {
-          consider_hit<MODE, COUNT, WANT_N, RES>(S, C, st, n_boxes, h0, t2.x, u2.x, v2.x, s0, a0, b0, c0);
-          consider_hit<MODE, COUNT, WANT_N, RES>(S, C, st, n_boxes, h1, t2.y, u2.y, v2.y, s1, a1, b1, c1);
+          consider_hit<MODE, COUNT, WANT_N, RES>(S, C, st, n_boxes, h0, t2.x, s0, c0);
+          consider_hit<MODE, COUNT, WANT_N, RES>(S, C, st, n_boxes, h1, t2.y, s1, c1);
           if (PRUNE) st.cull = st.best.t + (st.best.t * PT_SLACK_REL + PT_SLACK_ABS);
         }
       }
@@ -590,6 +616,7 @@ __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o,
     walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, S.quorum);
   } while (__ballot(!st.done()) != 0);
   best = st.best;
+  if (!ANY) hit_finish<MODE, RES>(S, C, o, d, best, WANT_N && S.n_tex != 0, WANT_N);
   return ANY ? st.found : st.best.slot != 0xffffffffu;
 }
 

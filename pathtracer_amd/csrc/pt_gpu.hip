@@ -112,6 +112,7 @@ struct PtScene {
   unsigned long long *h_stats = nullptr;   // pinned
   bool count_stats = false;
   bool profile = false;
+  uint32_t tail_paths = 0;                 // a batch with at most this many live paths is finished by k_tail (0: never)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   PtProfile prof{};
   // What the launches of the call in progress use: the scene's own workspace and counter block, or
@@ -447,6 +448,37 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
 }
 
 template <int MODE, bool COUNT>
+static int launch_tail(PtScene *s, const PathFrame &F, int depth, uint32_t n, const QueueDev &q, hipStream_t st) {
+  const Plan &P = plan_of(s, MODE);
+  const SceneDev D = dev_of(s, MODE);
+  // The kernel holds a whole path's state beside the walk's: about 180 registers per lane.  Workgroups of 1024
+  // would have 128 and spill; 512 (or the plan's, if smaller) fit.  The plan's LDS layout and spill area were
+  // sized for its own workgroup size and hold the smaller one.
+  auto go = [&](auto BL) -> int {
+    constexpr int BLOCK = decltype(BL)::value;
+    const bool tex = s->dev.n_tex != 0;
+    auto k = P.resident ? (tex ? k_tail<MODE, BLOCK, COUNT, true, true> : k_tail<MODE, BLOCK, COUNT, true, false>)
+                        : (tex ? k_tail<MODE, BLOCK, COUNT, false, true> : k_tail<MODE, BLOCK, COUNT, false, false>);
+    int rc = allow_lds(k, P.lds_bytes);
+    if (rc != PT_OK) return rc;
+    // few paths, long dependent chains: spread the waves over every CU and let each claim little at a time
+    size_t g = ((size_t)n + 63) / 64;
+    if (g > P.max_blocks) g = P.max_blocks;
+    if (g < 1) g = 1;
+    const size_t waves = g * (size_t)(BLOCK / 64);
+    size_t run = ((size_t)n + 63) / 64 / waves;
+    if (run < 1) run = 1;
+    if (run > 4) run = 4;
+    hipLaunchKernelGGL(k, dim3((unsigned)g), dim3(BLOCK), P.lds_bytes, st, D, P.lds, (uint32_t)run, F, depth, n, q, s->aw->rad, s->acnt,
+                       s->d_stats);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+  };
+  if (P.block == 256) return go(std::integral_constant<int, 256>{});
+  return go(std::integral_constant<int, 512>{});
+}
+
+template <int MODE, bool COUNT>
 static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz,
                             const float *dx, const float *dy, const float *dz, float *t, int32_t *tri, float *u,
                             float *v, hipStream_t st) {
@@ -685,6 +717,12 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     if (q >= 1 && q <= 64) s->dev.quorum = (uint32_t)q;
   }
   s->max_depth = f.max_depth; s->max_depth4 = f.max_depth4; s->n_meshes = f.n_meshes;
+  // the tail kernel walks a vertex's visibility rays one light after the other: hand over later when there are many lights
+  s->tail_paths = 131072u / (1u + s->dev.n_lights);
+  if (const char *e = std::getenv("PT_TAIL")) {  // tuning knob: 0 switches the tail kernel off
+    const long v = std::atol(e);
+    if (v >= 0 && v <= (1l << 30)) s->tail_paths = (uint32_t)v;
+  }
   int rc = make_plan(s, false);
   if (rc == PT_OK) rc = make_plan(s, true);
   return rc;
@@ -982,6 +1020,26 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
       HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), st));
+      if (n <= s->tail_paths) {
+        // few paths left: one kernel follows each of them to its end
+        if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
+        rc = with_mode(o.trace_mode, [&](auto MM) -> int {
+          constexpr int M = decltype(MM)::value;
+          return cs ? launch_tail<M, true>(s, PF, depth, n, w.q[cur], st) : launch_tail<M, false>(s, PF, depth, n, w.q[cur], st);
+        });
+        if (rc != PT_OK) return rc;
+        if (prof) HIP_TRY(hipEventRecord(s->ev[1], st));
+        HIP_TRY(hipMemcpyAsync(s->h_cnt, cnt, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (prof) {
+          if ((rc = elapsed(0, 1, s->prof.tail_ms)) != PT_OK) return rc;
+          s->prof.tail_launches += 1;
+        }
+        c.rays_closest += s->h_cnt[6];
+        c.rays_shadow += (uint64_t)s->h_cnt[1] * s->dev.n_lights;
+        c.bounce_passes += s->h_cnt[7];
+        break;
+      }
       if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
       rc = with_mode(o.trace_mode, [&](auto MM) -> int {
         constexpr int M = decltype(MM)::value;

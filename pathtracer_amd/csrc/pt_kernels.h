@@ -324,16 +324,21 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
 
 // Does the path of queue entry i go on after a vertex whose closest hit is at t?  It does iff it
 // hit something and passes Russian roulette (camera.cpp:65, 118-119).
-__device__ __forceinline__ bool survives(const SceneDev &S, const PathFrame &F, int depth, const QueueDev &q, uint32_t i,
-                                         float t) {
+__device__ __forceinline__ bool survives_id(const SceneDev &S, const PathFrame &F, int depth, uint32_t id, float t) {
   if (t == __builtin_inff()) return false;
   if (F.max_depth > 0 && depth >= F.max_depth) return false;
   if (depth <= F.rr_min_depth) return true;  // the roulette draw exists only when depth > rr_min_depth
-  const uint32_t id = q.id()[i];
   PathRng rng;
   rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
   const uint32_t dim = 2u + (uint32_t)depth * F.dims_per_vertex + 3u * S.n_lights;
   return roulette_pass(F.rr_prob, rng.real(0.0f, 1.0f, dim));
+}
+__device__ __forceinline__ bool survives(const SceneDev &S, const PathFrame &F, int depth, const QueueDev &q, uint32_t i,
+                                         float t) {
+  if (t == __builtin_inff()) return false;
+  if (F.max_depth > 0 && depth >= F.max_depth) return false;
+  if (depth <= F.rr_min_depth) return true;
+  return survives_id(S, F, depth, q.id()[i], t);
 }
 
 // Closest hit for every queued ray.  The kernel also decides which paths go on after this
@@ -355,7 +360,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
         return true;
       },
       [&](uint64_t i, const RayState &st) {
-        const HitRec &h = st.best;
+        HitRec h = st.best;
+        hit_finish<MODE, RES>(S, C, st.o, st.d, h, S.n_tex != 0, true);
         hit.t()[i] = h.t;
         hit.nx()[i] = h.n.x; hit.ny()[i] = h.n.y; hit.nz()[i] = h.n.z;
         hit.mat()[i] = h.mat;
@@ -387,7 +393,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, u
         return true;
       },
       [&](uint64_t i, const RayState &st) {
-        const HitRec &h = st.best;
+        HitRec h = st.best;
+        hit_finish<MODE, RES>(S, C, st.o, st.d, h, u != nullptr || v != nullptr, false);
         t[i] = h.t;
         tri[i] = h.slot != 0xffffffffu ? (int32_t)(mode_wide(MODE) ? S.tri_id4[h.slot] : S.tris[h.slot].tri_id) : -1;
         if (u) u[i] = h.u;
@@ -600,6 +607,29 @@ __device__ __forceinline__ void sample_light(const SceneDev &S, PathRng &rng, ui
   w = scale(scale(scale(lke, c), y), inv_area_f);
 }
 
+// The bounce of a path that goes on (camera.cpp:120-156): next direction w and the new throughput.
+// m0 is the first float4 of the vertex's material; slot, bu, bv (triangle record and barycentrics of the
+// hit) are read only for a textured material.
+template <int MODE, bool TEX>
+__device__ __forceinline__ void bounce(const SceneDev &S, const PathFrame &F, PathRng &rng, uint32_t base, V3 nrm, float4 m0,
+                                       uint32_t slot, float bu, float bv, V3 &T, V3 &w) {
+  const V3 kd = mk(m0.x, m0.y, m0.z);
+  const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
+  const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
+  const uint32_t tex = __float_as_uint(m0.w);
+  const bool textured = TEX && tex != 0;                                // camera.cpp:121
+  V3 texel = mk(0, 0, 0);
+  if (textured) texel = texel_brdf(S, mode_wide(MODE), tex, slot, bu, bv);
+  if (F.sampling == PT_SAMPLE_COSINE) {
+    w = cosine_dir(nrm, rx, ry);
+    T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob_f);
+  } else {
+    w = uniform_dir(nrm, rx, ry);
+    const V3 brdf = textured ? texel : divs(kd, F.pi_f);                // camera.cpp:122-146
+    T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+  }
+}
+
 // One path vertex per work item.  Which paths survive was decided by k_trace_queue and
 // prefix-summed by k_scan_*, so a survivor is written straight to its place in `out`: chunk
 // offset + its rank among the chunk's survivors (wave ballot mask + popcount).
@@ -673,7 +703,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
           const uint32_t mat_id = hit.mat()[i];
           const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
           const float4 m0 = mp[0], m1 = mp[1];
-          const V3 kd = mk(m0.x, m0.y, m0.z), ke = mk(m1.x, m1.y, m1.z);
+          const V3 ke = mk(m1.x, m1.y, m1.z);
           // direct light: every light at every vertex, camera.cpp:96-115
           V3 local = mk(0, 0, 0);
           for (uint32_t l = 0; l < S.n_lights; ++l) {
@@ -695,21 +725,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
           if (cont) local = add(local, ke);  // camera.cpp:154
           L = add(L, mul(T, local));
           if (cont) {
-            const float rx = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 1u);
-            const float ry = rng.real(0.0f, 1.0f, base + 3u * S.n_lights + 2u);
             V3 w;
-            const uint32_t tex = __float_as_uint(m0.w);
-            const bool textured = TEX && tex != 0;                                // camera.cpp:121
-            V3 texel = mk(0, 0, 0);
-            if (textured) texel = texel_brdf(S, mode_wide(MODE), tex, hit.slot()[i], hit.u()[i], hit.v()[i]);
-            if (F.sampling == PT_SAMPLE_COSINE) {
-              w = cosine_dir(nrm, rx, ry);
-              T = divs(mul(T, textured ? scale(texel, F.pi_f) : kd), F.rr_prob_f);
-            } else {
-              w = uniform_dir(nrm, rx, ry);
-              const V3 brdf = textured ? texel : divs(kd, F.pi_f);                // camera.cpp:122-146
-              T = divs(scale(mul(T, brdf), fabsf(dot(nrm, w))), F.pdf_f);         // camera.cpp:155-156
+            uint32_t slot = 0;
+            float bu = 0, bv = 0;
+            if (TEX && __float_as_uint(m0.w) != 0) {
+              slot = hit.slot()[i]; bu = hit.u()[i]; bv = hit.v()[i];
             }
+            bounce<MODE, TEX>(S, F, rng, base, nrm, m0, slot, bu, bv, T, w);
             o = x;  // no offset along the normal, camera.cpp:155
             d = w;
             alive = true;
@@ -735,6 +757,132 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
   if (COUNT && PHASE == 0) {
     wave_add64(stats + 2, nb);
     wave_add64(stats + 3, nt);
+  }
+}
+
+// The tail of a batch: once few paths are left, every pass of the wavefront pipeline costs its fixed
+// price (launches, a pass over mostly empty queues, the slowest ray of the pass) for almost no work.
+// This kernel takes the remaining paths and follows each one to its end, one path per lane: closest
+// hit, the light loop with its visibility walks, roulette, bounce, again.  The operations on a path and
+// their order are those of k_trace_queue + k_shade, so the radiance is the same bit for bit.
+// cnt[1] += vertices that hit something, cnt[6] += closest-hit rays, cnt[7] = max(depth levels done).
+template <int MODE, int BLOCK, bool COUNT, bool RES, bool TEX>
+__global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, LdsPlan plan, uint32_t kRun, PathFrame F, int depth0, uint32_t n,
+                                                QueueDev in, RadDev rad, uint32_t *cnt, unsigned long long *stats) {
+  uint32_t stk;
+  const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t nb = 0, nt = 0, sb = 0, stt = 0, n_hit = 0, n_rays = 0, levels = 0;
+  uint32_t *head = cnt + 2;
+  // paths of the claimed run not handed out yet (the same in all lanes); a lane whose path has ended
+  // stores its radiance and takes the next one, so the wave stays full while the queue lasts
+  uint64_t pool = 0, pool_end = 0;
+  bool more = true;
+  bool alive = false, mine = false;
+  V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(0, 0, 0), L = mk(0, 0, 0);
+  uint32_t id = 0;
+  int depth = depth0;
+  for (;;) {
+    const unsigned long long m_alive = __ballot(alive);
+    const uint32_t n_idle = 64u - (uint32_t)__popcll(m_alive);
+    if ((n_idle >= 8u && (more || pool < pool_end)) || m_alive == 0) {
+      if (!alive && mine) {
+        rad.ch(0)[id] = L.x; rad.ch(1)[id] = L.y; rad.ch(2)[id] = L.z;
+        const uint32_t done = (uint32_t)(depth - depth0);
+        if (done > levels) levels = done;
+        mine = false;
+      }
+      if (pool >= pool_end && more) {
+        const uint32_t run = next_run(head, kRun);
+        if ((uint64_t)run * 64u >= n) {
+          more = false;
+        } else {
+          pool = (uint64_t)run * 64u;
+          const uint64_t e = ((uint64_t)run + kRun) * 64u;
+          pool_end = e < n ? e : n;
+        }
+      }
+      if (!alive) {
+        const unsigned long long idle = ~m_alive;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        const uint64_t i = pool + rank;
+        if (i < pool_end) {
+          o = mk(in.ox()[i], in.oy()[i], in.oz()[i]);
+          d = mk(in.dx()[i], in.dy()[i], in.dz()[i]);
+          T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
+          L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
+          id = in.id()[i];
+          depth = depth0;
+          alive = true;
+          mine = true;
+        }
+      }
+      pool = pool_end - pool > n_idle ? pool + n_idle : pool_end;
+      if (__ballot(alive) == 0) {
+        if (!more && pool >= pool_end) break;
+        continue;
+      }
+    }
+    if (alive) {
+      ++n_rays;
+      HitRec h;
+      const bool got = walk<MODE, false, COUNT, true, RES>(S, C, o, d, stk, BLOCK, h, nb, nt);
+      if (!got) {  // camera.cpp:65-66
+        L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
+        alive = false;
+      } else {
+        ++n_hit;
+        const V3 x = add(o, scale(d, h.t));                                  // camera.cpp:68
+        V3 nrm = normalize(h.n);                                             // camera.cpp:69
+        if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);                   // camera.cpp:72-73
+        PathRng rng;
+        rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
+        const uint32_t base = 2u + (uint32_t)depth * F.dims_per_vertex;
+        const float4 *mp = reinterpret_cast<const float4 *>(S.mats + h.mat);
+        const float4 m0 = mp[0], m1 = mp[1];
+        V3 local = mk(0, 0, 0);
+        for (uint32_t l = 0; l < S.n_lights; ++l) {  // camera.cpp:96-115
+          V3 to, w;
+          sample_light(S, rng, base, l, x, nrm, to, w);
+          HitRec sh;
+          if (!walk<MODE, true, COUNT, false, RES>(S, C, x, to, stk, BLOCK, sh, sb, stt)) continue;
+          local = add(local, w);
+        }
+        const bool cont = survives_id(S, F, depth, id, h.t);                 // camera.cpp:118-119
+        if (cont) local = add(local, mk(m1.x, m1.y, m1.z));                  // camera.cpp:154
+        L = add(L, mul(T, local));
+        if (cont) {
+          V3 w;
+          bounce<MODE, TEX>(S, F, rng, base, nrm, m0, h.slot, h.u, h.v, T, w);
+          o = x;  // no offset along the normal, camera.cpp:155
+          d = w;
+        } else {
+          alive = false;
+        }
+      }
+      ++depth;
+    }
+  }
+  {
+    uint32_t a = n_hit, b = n_rays, c = levels;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off);
+      b += __shfl_down(b, off);
+      const uint32_t c2 = __shfl_down(c, off);
+      c = c2 > c ? c2 : c;
+    }
+    if (lane == 0) {
+      if (a) atomicAdd(&cnt[1], a);
+      if (b) atomicAdd(&cnt[6], b);
+      if (c) atomicMax(&cnt[7], c);
+    }
+  }
+  if (COUNT) {
+    wave_add64(stats + 0, nb);
+    wave_add64(stats + 1, nt);
+    wave_add64(stats + 2, sb);
+    wave_add64(stats + 3, stt);
   }
 }
 

@@ -133,7 +133,9 @@ def test_counters_and_profile(api):
     _, c = ds.render(cam, 64, 36, 4, seed=1)
     p = ds.read_profile()
     assert c.node_boxes > c.rays_closest and c.tri_tests > 0 and c.shadow_node_boxes > 0
-    assert p["trace_launches"] == c.bounce_passes and p["trace_ms"] > 0 and p["shade_ms"] > 0
+    # a frame this small is finished by the tail kernel from the first vertex on
+    assert p["trace_launches"] + p["tail_launches"] >= 1 and p["trace_ms"] + p["shade_ms"] + p["tail_ms"] > 0
+    assert p["trace_launches"] <= c.bounce_passes
     ds.count_stats(False)
     ds.profile(False)
     _, c2 = ds.render(cam, 64, 36, 4, seed=1)

@@ -67,6 +67,39 @@ def test_extensions_match_oracle(api):
     assert gc.bounce_passes <= 6 * 1
 
 
+@pytest.mark.parametrize("name,cam_kw,opt_kw", [
+    ("box", dict(vw=16, vh=9), dict()),
+    ("box", dict(vw=16, vh=9), dict(trace_mode=2)),
+    ("atrium_small", dict(vw=16, vh=9, aperture=0.05, focus=3.0), dict(max_depth=5)),
+    ("terrain_small", dict(origin=(0, 0.5, 0), euler=(0.15, 0, 0), vw=16, vh=9), dict()),
+])
+def test_tail_kernel_and_wavefront_passes_agree(api, monkeypatch, name, cam_kw, opt_kw):
+    """The last paths of a batch are followed to their ends by one kernel instead of one pass per depth
+    level.  Whatever the hand-over point — never (PT_TAIL=0), the default, after two levels' worth of
+    attrition, or from the first vertex on — the radiance sums are the same bit for bit, the ray counts
+    are equal, and they are the oracle's."""
+    w = util.world(name)
+    W, H, spp = 192, 108, 4
+    ref, rc = w.render(O.default_camera(**cam_kw), W, H, spp, seed=13, opt=O.default_options(**{k: v for k, v in opt_kw.items() if k != "trace_mode"}), rng=0, form=1)
+    imgs, cnts = [], []
+    for tail in ("0", None, "30000", str(1 << 30)):
+        if tail is None:
+            monkeypatch.delenv("PT_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("PT_TAIL", tail)   # read when the scene is uploaded
+        ds = api.DeviceScene(w.export())
+        img, c = ds.render(api.make_camera(**cam_kw), W, H, spp, seed=13, opt=api.make_options(**opt_kw))
+        ds.close()
+        imgs.append(img)
+        cnts.append(c)
+    monkeypatch.delenv("PT_TAIL", raising=False)
+    for img, c in zip(imgs[1:], cnts[1:]):
+        assert (util.bits(img) == util.bits(imgs[0])).all()
+        assert (c.paths, c.rays_closest, c.rays_shadow, c.bounce_passes) == (cnts[0].paths, cnts[0].rays_closest, cnts[0].rays_shadow, cnts[0].bounce_passes)
+    assert_images_match(ref, imgs[0])
+    assert abs(int(cnts[0].rays_closest) - int(rc.rays_closest)) <= 2e-3 * rc.rays_closest
+
+
 def test_sample_split_is_exact(api):
     """Any split of the sample range over calls gives the same sums as long as the order of
     the additions per pixel is kept: 0..7 in one call == 0..3 then 4..7."""
