@@ -118,6 +118,31 @@ __device__ __forceinline__ V3 rotate9(const double *c, V3 p) {
   return r;
 }
 
+// sin and cos of an angle in [0, 2*pi] in double precision, for the reference's cos(2*M_PI*y) / sin(2*M_PI*y)
+// (camera.cpp:83-84).  The device library's sin() and cos() each reduce the argument for any magnitude and cost
+// some hundred instructions apiece; here one reduction by multiples of pi/2 (two-constant Cody-Waite, exact
+// for the five multiples that occur) serves both, followed by the classic degree-13/14 kernels on
+// [-pi/4, pi/4] (error under one unit in the last place of a double).  The results are multiplied by a float
+// and narrowed to float, so a last-place difference from the host's libm shows in about one float out of 2^29.
+__device__ __forceinline__ void sincos_0_2pi(double a, double &sn, double &cs) {
+  const double q = __builtin_rint(a * 6.36619772367581382433e-01);        // a * 2/pi
+  double r = __builtin_fma(-q, 1.57079632679489655800e+00, a);             // pi/2, high part
+  r = __builtin_fma(-q, 6.12323399573676603587e-17, r);                    // pi/2, low part
+  const double z = r * r;
+  const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                    z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+  const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double c = w + (((1.0 - w) - hz) + z * pc);
+  const int n = (int)q & 3;
+  sn = (n & 1) ? c : s;
+  cs = (n & 1) ? s : c;
+  if (n & 2) sn = -sn;
+  if ((n + 1) & 2) cs = -cs;
+}
+
 __device__ __forceinline__ void camera_ray(const FrameDev &F, int px, int py, PathRng &rng, V3 &o, V3 &d) {
   // camera.cpp:162-167: float arithmetic on x and y, z prepared in double by the host
   const float x = ((float)px - (float)F.W / 2) * F.vw / (float)F.W;
@@ -127,7 +152,9 @@ __device__ __forceinline__ void camera_ray(const FrameDev &F, int px, int py, Pa
     const float u1 = rng.real(0.0f, 1.0f, 0), u2 = rng.real(0.0f, 1.0f, 1);
     const float r = F.aperture * sqrtf(u1);
     const double ph = 2 * M_PI * (double)u2;
-    const V3 lens = mk((float)(cos(ph) * (double)r), (float)(sin(ph) * (double)r), 0.0f);
+    double sp, cp;
+    sincos_0_2pi(ph, sp, cp);
+    const V3 lens = mk((float)(cp * (double)r), (float)(sp * (double)r), 0.0f);
     const float s = F.focus / dc.z;
     const V3 pf = scale(dc, s);
     const float inv_s = dc.z / F.focus;
@@ -530,7 +557,9 @@ __device__ __forceinline__ V3 uniform_dir(V3 n, float x, float y) {
   const float theta = (float)fmax(0.0, (double)(1.0f - phi * phi));
   const float st = sqrtf(theta);
   const double ang = 2 * M_PI * (double)y;
-  V3 v = mk((float)(cos(ang) * (double)st), (float)(sin(ang) * (double)st), phi);
+  double sa, ca;
+  sincos_0_2pi(ang, sa, ca);
+  V3 v = mk((float)(ca * (double)st), (float)(sa * (double)st), phi);
   v = normalize(v);
   return dot(v, n) < 0.0f ? neg(v) : v;
 }
@@ -539,7 +568,9 @@ __device__ __forceinline__ V3 cosine_dir(V3 n, float x, float y) {
   const float r = sqrtf(x);
   const float lz = sqrtf(fmaxf(0.0f, 1.0f - x));
   const double ang = 2 * M_PI * (double)y;
-  const float lx = (float)(cos(ang) * (double)r), ly = (float)(sin(ang) * (double)r);
+  double sa, ca;
+  sincos_0_2pi(ang, sa, ca);
+  const float lx = (float)(ca * (double)r), ly = (float)(sa * (double)r);
   const float s = copysignf(1.0f, n.z);
   const float a = -1.0f / (s + n.z);
   const float b = n.x * n.y * a;
@@ -672,19 +703,22 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
     if (active) {
       id = in.id()[i];
       const float t = hit.t()[i];
-      if (PHASE != 1) {
-        T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
-        L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
-      }
       if (t == __builtin_inff()) {  // camera.cpp:65-66
-        L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
+        if (PHASE != 1) {
+          T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
+          L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
+          L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
+        }
       } else {
         did_hit = true;
-        o = mk(in.ox()[i], in.oy()[i], in.oz()[i]);
-        d = mk(in.dx()[i], in.dy()[i], in.dz()[i]);
-        const V3 x = add(o, scale(d, t));                               // camera.cpp:68
-        V3 nrm = normalize(mk(hit.nx()[i], hit.ny()[i], hit.nz()[i]));        // camera.cpp:69
-        if (dot(nrm, normalize(d)) > 0.0f) nrm = neg(nrm);              // camera.cpp:72-73
+        V3 x, nrm;
+        {
+          const V3 ro = mk(in.ox()[i], in.oy()[i], in.oz()[i]);
+          const V3 rd = mk(in.dx()[i], in.dy()[i], in.dz()[i]);
+          x = add(ro, scale(rd, t));                                          // camera.cpp:68
+          nrm = normalize(mk(hit.nx()[i], hit.ny()[i], hit.nz()[i]));         // camera.cpp:69
+          if (dot(nrm, normalize(rd)) > 0.0f) nrm = neg(nrm);                 // camera.cpp:72-73
+        }
 
         PathRng rng;
         rng.init(F.seed, id % F.P, F.sample0 + (id / F.P) * F.stride);
@@ -700,11 +734,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
             sd.wx()[k] = w.x; sd.wy()[k] = w.y; sd.wz()[k] = w.z;
           }
         } else {
-          const uint32_t mat_id = hit.mat()[i];
-          const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
-          const float4 m0 = mp[0], m1 = mp[1];
-          const V3 ke = mk(m1.x, m1.y, m1.z);
-          // direct light: every light at every vertex, camera.cpp:96-115
+          // direct light: every light at every vertex, camera.cpp:96-115.  Only the hit point, the normal and
+          // the generator are alive across the visibility walks; the rest of the path's state is loaded after them.
           V3 local = mk(0, 0, 0);
           for (uint32_t l = 0; l < S.n_lights; ++l) {
             if (PHASE == 0) {
@@ -720,6 +751,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
               local = add(local, mk(sd.wx()[k], sd.wy()[k], sd.wz()[k]));
             }
           }
+          T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
+          L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
+          const uint32_t mat_id = hit.mat()[i];
+          const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
+          const float4 m0 = mp[0], m1 = mp[1];
+          const V3 ke = mk(m1.x, m1.y, m1.z);
 
           // Russian roulette (camera.cpp:118-119) was drawn by k_trace_queue: `cont`
           if (cont) local = add(local, ke);  // camera.cpp:154

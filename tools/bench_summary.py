@@ -14,4 +14,4 @@ for f in sys.argv[1:]:
     for o in r.get("other_configs", []):
         print("    %-12s %.0f Mrays/s %.1f ms" % (o["workload"].split(":")[0], o["value"], o["ms_per_step"]),
               {k: round(v, 1) for k, v in o["kernel_ms_per_step"].items()},
-              "boxes/ray %.1f tris/ray %.2f" % (o["node_boxes_per_ray"] or 0, o["tri_tests_per_ray"] or 0))
+              "boxes/ray %.1f tris/ray %.2f rays/sample %.1f" % (o.get("node_boxes_per_ray") or 0, o.get("tri_tests_per_ray") or 0, o.get("rays_per_sample") or 0))

@@ -1,31 +1,51 @@
-"""Turns a counter summary (tools/pmc_summary.py) into profiles/pmc_<config>.json: HBM-side bytes
-per launch of the closest-hit kernel.  FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-tallies the 128-byte read requests of this kernel's coalesced queue reads at 64 bytes, so it is
-doubled (checked against the known 24 bytes per ray the kernel reads from the ray queue).
-Also: vector instructions per launch of that kernel (SQ_INSTS_VALU) and, when a second summary with
-SQ_THREAD_CYCLES_VALU is given, the mean number of active lanes per vector instruction
-(SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; 64 = all lanes).
+"""Turns a counter summary (tools/pmc_summary.py) into profiles/pmc_<config>.json: per launch of the
+closest-hit kernel (k_trace_queue, the plain instantiation without work counters), the HBM-side bytes,
+the L2 hit rate, the wave-level vector instructions, the share of LDS cycles lost to bank conflicts and
+the mean number of active lanes per vector instruction; plus fetch / write bytes of every kernel.
+FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte read requests of wide
+coalesced reads at 64 bytes, so it is doubled (checked in round 1 against the 24 bytes per ray this
+kernel reads from the ray queue when the scene itself sits in LDS).
 usage: pmc_to_traffic.py <pmc_summary.json> <config> [<pmc_lanes.json>] > profiles/pmc_<config>.json"""
 import json, sys
+
+
+def is_plain_trace(name):
+    if "k_trace_queue<" not in name:
+        return False
+    args = name.split("<", 1)[1].split(">")[0].split(",")
+    return len(args) >= 3 and args[2].strip() == "false"   # MODE, BLOCK, COUNT, ...
+
 
 s = json.load(open(sys.argv[1]))
 out = {"config": sys.argv[2], "source": sys.argv[1], "kernels": {}}
 for name, c in s.items():
-    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-        continue
     n = max(1, int(c["_dispatches"]))
-    out["kernels"][name] = {
-        "dispatches": n,
-        "fetch_bytes_per_launch": 2.0 * c["FETCH_SIZE"] * 1024.0 / n,
-        "write_bytes_per_launch": c["WRITE_SIZE"] * 1024.0 / n,
-    }
-    if "k_trace_queue" in name and "false" in name.split("<")[1].split(",")[2]:
-        k = out["kernels"][name]
-        out["trace_closest_hbm_bytes_per_launch"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-        if "SQ_INSTS_VALU" in c:
-            out["trace_closest_valu_insts_per_launch"] = c["SQ_INSTS_VALU"] / n
+    k = {"dispatches": n}
+    if "FETCH_SIZE" in c:
+        k["fetch_bytes_per_launch"] = 2.0 * c["FETCH_SIZE"] * 1024.0 / n
+    if "WRITE_SIZE" in c:
+        k["write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024.0 / n
+    if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
+        k["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "SQ_INSTS_VALU" in c:
+        k["valu_insts_per_launch"] = c["SQ_INSTS_VALU"] / n
+        k["salu_insts_per_launch"] = c.get("SQ_INSTS_SALU", 0) / n
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        k["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
+    if c.get("SQ_WAVE_CYCLES"):
+        k["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
+        k["active_inst_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
+    if len(k) > 1 and not name.startswith("void at::") and "rocclr" not in name:
+        out["kernels"][name] = k
+    if is_plain_trace(name):
+        if "fetch_bytes_per_launch" in k and "write_bytes_per_launch" in k:
+            out["trace_closest_hbm_bytes_per_launch"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+        for src, dst in (("l2_hit_rate", "trace_closest_l2_hit_rate"), ("valu_insts_per_launch", "trace_closest_valu_insts_per_launch"),
+                         ("lds_conflict_frac", "trace_closest_lds_conflict_frac"), ("wait_any_frac", "trace_closest_wait_any_frac")):
+            if src in k:
+                out[dst] = k[src]
 if len(sys.argv) > 3:
     for name, c in json.load(open(sys.argv[3])).items():
-        if "k_trace_queue" in name and "false" in name.split("<")[1].split(",")[2] and c.get("SQ_ACTIVE_INST_VALU"):
+        if is_plain_trace(name) and c.get("SQ_ACTIVE_INST_VALU"):
             out["trace_closest_active_lanes"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
