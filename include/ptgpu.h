@@ -267,6 +267,19 @@ int pt_render_dev(PtScene *scene, const PtCamera *cam, int W, int H,
                   const PtOptions *opt, float *accum_rgb_sum_dev,
                   PtCounters *counters, void *stream);
 
+/* Seam B over several devices of one node (camera.cpp:171-200; the reference's only parallelism is
+ * parallel_for over OS threads, camera.cpp:14-39).  scenes[g] is a copy of the same scene on its own
+ * device (pt_scene_upload once per device).  The samples spp_begin + j*spp_stride, j in [0, spp_count),
+ * are dealt round-robin: device g renders j = g, g + n, ... on a host thread of its own; random numbers
+ * depend on the global sample index only, so the union is the set one device would render.  The per-device
+ * radiance sums are merged by ONE all-reduce (RCCL, float32 sum over 3*W*H values, loaded from librccl
+ * when n > 1) and added to accum_rgb_sum (host memory).  With n == 1 the result equals pt_render's bit
+ * for bit; with n > 1 it equals it up to the order of the float additions.  counters are summed over
+ * the devices (bounce_passes: the maximum). */
+int pt_render_multi(PtScene *const *scenes, int n_scenes, const PtCamera *cam, int W, int H,
+                    uint32_t spp_begin, uint32_t spp_count, uint64_t seed, const PtOptions *opt,
+                    float *accum_rgb_sum, PtCounters *counters);
+
 /* Size of the static device buffer pt_render_dev_static works in. */
 #define PT_STATIC_SCRATCH_BYTES (64u << 20)
 

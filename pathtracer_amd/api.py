@@ -80,7 +80,7 @@ EXPORTS = [
     "pt_scene_free", "pt_scene_info", "pt_scene_check", "pt_scene_count_stats", "pt_scene_read_stats", "pt_scene_profile",
     "pt_scene_read_profile", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_trace_any", "pt_trace_hits", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
-    "pt_philox4x32", "pt_roulette_pass", "pt_render_dev_static", "pt_static_scratch_bytes",
+    "pt_philox4x32", "pt_roulette_pass", "pt_render_dev_static", "pt_static_scratch_bytes", "pt_render_multi",
 ]
 
 
@@ -129,6 +129,8 @@ def lib():
         L.pt_render_dev.argtypes = L.pt_render.argtypes + [C.c_void_p]
         L.pt_render_dev_static.argtypes = L.pt_render_dev.argtypes
         L.pt_static_scratch_bytes.restype = C.c_uint64
+        L.pt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(PtCamera), C.c_int, C.c_int, C.c_uint32,
+                                      C.c_uint32, C.c_uint64, C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtCounters)]
         L.pt_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         L.pt_philox4x32.argtypes = [C.c_void_p] * 3
         L.pt_philox4x32.restype = None
@@ -249,6 +251,21 @@ def scene_check(arrays):
     info = PtSceneInfo()
     _check(lib().pt_scene_check(C.byref(d), C.byref(info)))
     return {k: int(getattr(info, k)) for k, _ in info._fields_}
+
+
+def render_multi(scenes, cam, W, H, spp_count, spp_begin=0, seed=0, opt=None, accum=None):
+    """pt_render_multi: the frame's samples dealt over the devices of `scenes` (DeviceScene copies of one scene,
+    one per device), merged by one all-reduce and added to `accum`.  Returns (accum, PtCounters)."""
+    if accum is None:
+        accum = np.zeros((H, W, 3), np.float32)
+    if accum.dtype != np.float32 or accum.shape != (H, W, 3) or not accum.flags.c_contiguous:
+        raise ValueError("accum must be a contiguous float32 [H,W,3] array")
+    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
+    cnt = PtCounters()
+    o = opt if opt is not None else make_options()
+    _check(lib().pt_render_multi(handles, len(scenes), C.byref(cam), W, H, spp_begin, spp_count, seed, C.byref(o),
+                                 _p(accum), C.byref(cnt)))
+    return accum, cnt
 
 
 class DeviceScene:

@@ -34,7 +34,11 @@ void Camera::render(const Scene &scene, int samples, std::function<void()> cb, i
   pixels.assign(np, vec(0, 0, 0));  // camera.cpp:177-179
   memset(&counters, 0, sizeof(counters));
   if (samples <= 0) return;
-  PtScene *dev = scene.device_scene(device);
+  std::vector<PtScene *> devs;
+  if (devices.size() > 1)
+    for (int d : devices) devs.push_back(scene.device_scene(d));
+  else
+    devs.push_back(scene.device_scene(devices.size() == 1 ? devices[0] : device));
   PtOptions opt = options;
   opt.bgcolor[0] = bgcolor.x; opt.bgcolor[1] = bgcolor.y; opt.bgcolor[2] = bgcolor.z;
   const PtCamera cam = abi_camera();
@@ -44,8 +48,9 @@ void Camera::render(const Scene &scene, int samples, std::function<void()> cb, i
   for (int done = 0; done < samples; done += step) {
     const int now = samples - done < step ? samples - done : step;
     PtCounters c;
-    if (pt_render(dev, &cam, OUTW, OUTH, (uint32_t)done * stride, (uint32_t)now, seed, &opt, sums.data(), &c) != PT_OK)
-      throw std::runtime_error(std::string("pt_render: ") + pt_last_error());
+    if (pt_render_multi(devs.data(), (int)devs.size(), &cam, OUTW, OUTH, spp_begin + (uint32_t)done * stride, (uint32_t)now, seed, &opt,
+                        sums.data(), &c) != PT_OK)
+      throw std::runtime_error(std::string("pt_render_multi: ") + pt_last_error());
     counters.paths += c.paths; counters.rays_closest += c.rays_closest; counters.rays_shadow += c.rays_shadow;
     counters.node_boxes += c.node_boxes; counters.tri_tests += c.tri_tests; counters.bounce_passes += c.bounce_passes;
     // the reference keeps a running mean of radiance*255 (camera.cpp:188-190); sum/n*255 is

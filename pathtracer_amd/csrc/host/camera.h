@@ -24,6 +24,8 @@ class Camera {
   PtOptions options;
   uint64_t seed = 0;
   int device = 0;
+  std::vector<int> devices;        // more than one entry: the samples are dealt over these devices (pt_render_multi)
+  uint32_t spp_begin = 0;          // global index of this render's first sample (a shard of a larger frame)
   PtCounters counters{};           // work done by the last render()
 
   explicit Camera(const vec &origin, const vec &direction = vec(0, 0, 0));

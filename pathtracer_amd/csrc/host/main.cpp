@@ -18,7 +18,7 @@ static void usage(const char *argv0) {
   std::fprintf(stderr,
                "usage: %s scene.obj [-o out.ppm] [--spp N] [--width W] [--height H] [--vw A --vh B]\n"
                "          [--origin x,y,z] [--euler a,b,c] [--fov deg] [--aperture r --focus d]\n"
-               "          [--max-depth k] [--cosine] [--exact] [--seed s] [--device i] [--progress]\n"
+               "          [--max-depth k] [--cosine] [--exact] [--seed s] [--device i] [--devices n] [--progress]\n"
                "          [--save-cache scene.ptscene]   (a .ptscene file is also accepted as the scene)\n"
                "          [--heatmap]   (instead of rendering: HitData::hits of every primary ray as a grey image)\n",
                argv0);
@@ -68,6 +68,11 @@ int main(int argc, char **argv) {
     else if (a == "--max-depth") cam.options.max_depth = std::atoi(need("--max-depth"));
     else if (a == "--seed") cam.seed = std::strtoull(need("--seed"), nullptr, 10);
     else if (a == "--device") cam.device = std::atoi(need("--device"));
+    else if (a == "--devices") {  // the samples dealt over devices 0..n-1, one all-reduce per callback
+      const int nd = std::atoi(need("--devices"));
+      cam.devices.clear();
+      for (int d = 0; d < nd; ++d) cam.devices.push_back(d);
+    }
     else if (a == "--cosine") cam.options.sampling = PT_SAMPLE_COSINE;
     else if (a == "--exact") cam.options.trace_mode = PT_TRACE_EXACT;
     else if (a == "--progress") progress = true;

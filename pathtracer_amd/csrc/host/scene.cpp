@@ -19,7 +19,8 @@ Scene::Scene(Scene &&o) noexcept { *this = std::move(o); }
 
 Scene &Scene::operator=(Scene &&o) noexcept {
   if (this != &o) {
-    if (dev_) pt_scene_free(dev_);
+    for (auto &d : dev_) pt_scene_free(d.second);
+    dev_.clear();
     meshes = std::move(o.meshes);
     materials = std::move(o.materials);
     textures = std::move(o.textures);
@@ -38,16 +39,15 @@ Scene &Scene::operator=(Scene &&o) noexcept {
       material_texture_ = std::move(o.material_texture_);
       point_desc();
     }
-    dev_ = o.dev_;
-    dev_ordinal_ = o.dev_ordinal_;
-    o.dev_ = nullptr;
+    dev_ = std::move(o.dev_);
+    o.dev_.clear();
     o.desc_ready_ = false;
   }
   return *this;
 }
 
 Scene::~Scene() {
-  if (dev_) pt_scene_free(dev_);
+  for (auto &d : dev_) pt_scene_free(d.second);
 }
 
 std::vector<int> Scene::lights() const {
@@ -164,21 +164,17 @@ const PtSceneDesc &Scene::desc() const {
 }
 
 PtScene *Scene::device_scene(int device) const {
-  if (dev_ && dev_ordinal_ == device) return dev_;
-  if (dev_) {
-    pt_scene_free(dev_);
-    dev_ = nullptr;
-  }
+  for (auto &d : dev_)
+    if (d.first == device) return d.second;
   PtScene *s = nullptr;
   if (pt_scene_upload(&desc(), device, &s) != PT_OK) throw std::runtime_error(std::string("pt_scene_upload: ") + pt_last_error());
-  dev_ = s;
-  dev_ordinal_ = device;
-  return dev_;
+  dev_.emplace_back(device, s);
+  return s;
 }
 
 void Scene::castrays(size_t n, const vec *origin, const vec *direction, HitData *out, int mode) const {
   if (n == 0) return;
-  PtScene *s = device_scene(dev_ordinal_ < 0 ? 0 : dev_ordinal_);
+  PtScene *s = device_scene(dev_.empty() ? 0 : dev_.front().first);
   std::vector<float> in(6 * n), t(n), u(n), v(n);
   std::vector<int32_t> tri(n);
   for (size_t i = 0; i < n; ++i) {

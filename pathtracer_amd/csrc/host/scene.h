@@ -50,7 +50,7 @@ class Scene {
   bool from_cache() const { return cached_; }
   // Fills a PtSceneDesc whose pointers refer to storage owned by this Scene.
   const PtSceneDesc &desc() const;
-  // Device copy (created on first use on `device`).
+  // Device copy (created on first use on `device`; copies on several devices are kept side by side).
   PtScene *device_scene(int device = 0) const;
 
  private:
@@ -66,8 +66,7 @@ class Scene {
   mutable std::vector<float> tri_uv_;            // only when a texture exists
   mutable std::vector<int32_t> material_texture_;
   mutable std::vector<PtTexture> tex_desc_;
-  mutable PtScene *dev_ = nullptr;
-  mutable int dev_ordinal_ = -1;
+  mutable std::vector<std::pair<int, PtScene *>> dev_;  // (device ordinal, copy); the first one serves castrays()
 };
 
 }  // namespace pt

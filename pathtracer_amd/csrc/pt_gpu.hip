@@ -19,6 +19,9 @@
 // PT_NO_RESIDENT, PT_SPLIT, PT_RES_REFILL, PT_VERBOSE); none is needed for normal use.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +29,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -1218,6 +1222,154 @@ int pt_render(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin,
   }
   (void)hipFree(d);
   return rc;
+}
+
+// ---------------------------------------------------------------- several devices, one all-reduce
+
+// RCCL is loaded on first use (a one-device call never needs it) and by name only, so that a process
+// that already holds an RCCL (PyTorch's) shares it.
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;
+static std::vector<std::pair<std::vector<int>, std::vector<ncclComm_t>>> g_comms;  // per device list, kept for the process
+
+static int rccl_load() {
+  if (g_rccl.lib) return PT_OK;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(PT_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
+  RcclApi a;
+  a.lib = h;
+  a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+  a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+  a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+  a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!a.CommInitAll || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString)
+    return fail(PT_ERR_DEVICE, "librccl lacks an expected symbol");
+  g_rccl = a;
+  return PT_OK;
+}
+
+static int rccl_comms(const std::vector<int> &devices, std::vector<ncclComm_t> &out) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  int rc = rccl_load();
+  if (rc != PT_OK) return rc;
+  for (auto &e : g_comms)
+    if (e.first == devices) {
+      out = e.second;
+      return PT_OK;
+    }
+  std::vector<ncclComm_t> comms(devices.size());
+  const ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devices.size(), devices.data());
+  if (r != ncclSuccess) return fail(PT_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+  g_comms.emplace_back(devices, comms);
+  out = comms;
+  return PT_OK;
+}
+
+int pt_render_multi(PtScene *const *scenes, int n, const PtCamera *cam, int W, int H, uint32_t spp_begin,
+                    uint32_t spp_count, uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters) {
+  if (!scenes || n <= 0 || !accum) return fail(PT_ERR_INVALID, "null scenes or accumulator");
+  if (W <= 0 || H <= 0 || (uint64_t)W * (uint64_t)H > (1ull << 28)) return fail(PT_ERR_INVALID, "bad image size");
+  std::vector<int> devices;
+  for (int g = 0; g < n; ++g) {
+    if (!scenes[g]) return fail(PT_ERR_INVALID, "null scene");
+    for (int d : devices)
+      if (d == scenes[g]->device) return fail(PT_ERR_INVALID, "two scenes on one device");
+    devices.push_back(scenes[g]->device);
+  }
+  if (n == 1) return pt_render(scenes[0], cam, W, H, spp_begin, spp_count, seed, opt, accum, counters);
+  PtOptions o;
+  if (opt) o = *opt; else pt_options_default(&o);
+  const uint32_t stride = o.spp_stride ? o.spp_stride : 1;
+  DeviceGuard guard;
+  const size_t count = (size_t)W * H * 3, bytes = count * sizeof(float);
+  std::vector<float *> bufs((size_t)n, nullptr);
+  std::vector<int> rcs((size_t)n, PT_OK);
+  std::vector<std::string> errs((size_t)n);
+  std::vector<PtCounters> cs((size_t)n);
+  auto cleanup = [&]() {
+    for (int g = 0; g < n; ++g)
+      if (bufs[g]) {
+        (void)hipSetDevice(devices[g]);
+        (void)hipFree(bufs[g]);
+      }
+  };
+  // one host thread per device: its share of the samples into a zeroed accumulator on that device
+  auto work = [&](int g) {
+    memset(&cs[g], 0, sizeof(PtCounters));
+    hipError_t e = hipSetDevice(devices[g]);
+    if (e == hipSuccess) e = hipMalloc(&bufs[g], bytes);
+    if (e == hipSuccess) e = hipMemset(bufs[g], 0, bytes);
+    if (e != hipSuccess) {
+      rcs[g] = PT_ERR_DEVICE;
+      errs[g] = std::string("device accumulator: ") + hipGetErrorString(e);
+      return;
+    }
+    PtOptions og = o;
+    og.spp_stride = stride * (uint32_t)n;
+    const uint32_t mine = spp_count > (uint32_t)g ? (spp_count - (uint32_t)g + (uint32_t)n - 1) / (uint32_t)n : 0;
+    rcs[g] = pt_render_dev(scenes[g], cam, W, H, spp_begin + (uint32_t)g * stride, mine, seed, &og, bufs[g], &cs[g], nullptr);
+    if (rcs[g] != PT_OK) errs[g] = g_err;
+    else if ((e = hipDeviceSynchronize()) != hipSuccess) {
+      rcs[g] = PT_ERR_DEVICE;
+      errs[g] = std::string("render: ") + hipGetErrorString(e);
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int g = 1; g < n; ++g) th.emplace_back(work, g);
+    work(0);
+    for (auto &t : th) t.join();
+  }
+  for (int g = 0; g < n; ++g)
+    if (rcs[g] != PT_OK) {
+      cleanup();
+      return fail(rcs[g], "device " + std::to_string(devices[g]) + ": " + errs[g]);
+    }
+  {
+    std::vector<ncclComm_t> comms;
+    int rc = rccl_comms(devices, comms);
+    if (rc != PT_OK) { cleanup(); return rc; }
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int g = 0; g < n && r == ncclSuccess; ++g) {
+      (void)hipSetDevice(devices[g]);
+      r = g_rccl.AllReduce(bufs[g], bufs[g], count, ncclFloat, ncclSum, comms[g], nullptr);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) { cleanup(); return fail(PT_ERR_DEVICE, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r)); }
+    for (int g = 0; g < n; ++g) {
+      (void)hipSetDevice(devices[g]);
+      const hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) { cleanup(); return fail(PT_ERR_DEVICE, std::string("all-reduce: ") + hipGetErrorString(e)); }
+    }
+  }
+  // every device now holds the frame's sums; the first one's copy goes to the caller
+  std::vector<float> host(count);
+  (void)hipSetDevice(devices[0]);
+  const hipError_t e = hipMemcpy(host.data(), bufs[0], bytes, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("copy of the result: ") + hipGetErrorString(e));
+  for (size_t i = 0; i < count; ++i) accum[i] += host[i];
+  if (counters) {
+    memset(counters, 0, sizeof(*counters));
+    for (int g = 0; g < n; ++g) {
+      counters->paths += cs[g].paths; counters->rays_closest += cs[g].rays_closest; counters->rays_shadow += cs[g].rays_shadow;
+      counters->node_boxes += cs[g].node_boxes; counters->tri_tests += cs[g].tri_tests;
+      counters->shadow_node_boxes += cs[g].shadow_node_boxes; counters->shadow_tri_tests += cs[g].shadow_tri_tests;
+      if (cs[g].bounce_passes > counters->bounce_passes) counters->bounce_passes = cs[g].bounce_passes;
+    }
+  }
+  return PT_OK;
 }
 
 int pt_resolve(const float *sum, size_t n, uint32_t spp, float *pixels) {

@@ -125,6 +125,49 @@ def test_device_pointer_entry_points(api):
     ds.close()
 
 
+def test_render_multi_on_one_device_equals_render(api):
+    """pt_render_multi with a single device is pt_render bit for bit (same samples, same additions), also as a
+    shard of a larger frame and through the host-side Camera."""
+    ds = api.DeviceScene(util.world("box").export())
+    cam = api.make_camera(vw=16, vh=9)
+    a, ca = ds.render(cam, 96, 54, 5, spp_begin=3, seed=4, opt=api.make_options(spp_stride=2))
+    b, cb = api.render_multi([ds], cam, 96, 54, 5, spp_begin=3, seed=4, opt=api.make_options(spp_stride=2))
+    assert (util.bits(a) == util.bits(b)).all() and ca.as_dict() == cb.as_dict()
+    with pytest.raises(api.PtError):
+        api.render_multi([ds, ds], cam, 96, 54, 5)      # two copies on one device
+    ds.close()
+
+
+def test_render_multi_over_all_devices(api):
+    """The samples dealt over every visible device and merged by one RCCL all-reduce: the frame one device
+    renders, up to the order of the float additions; ray counts add up exactly."""
+    n = api.device_count()
+    if n < 2:
+        pytest.skip("one device")
+    e = util.world("atrium_small").export()
+    scenes = [api.DeviceScene(e, device=g) for g in range(n)]
+    cam = api.make_camera(vw=16, vh=9)
+    one, c1 = scenes[0].render(cam, 160, 90, 16, seed=6)
+    many, cn = api.render_multi(scenes, cam, 160, 90, 16, seed=6)
+    np.testing.assert_allclose(many, one, rtol=2e-5, atol=1e-6)
+    assert (cn.paths, cn.rays_closest, cn.rays_shadow) == (c1.paths, c1.rays_closest, c1.rays_shadow)
+    for s in scenes:
+        s.close()
+
+
+def test_current_device_is_left_alone(api):
+    """Entry points that work on another device than the caller's current one restore the caller's."""
+    import torch
+    if api.device_count() < 2:
+        pytest.skip("one device")
+    torch.cuda.set_device(0)
+    ds = api.DeviceScene(util.world("box").export(), device=1)
+    ds.render(api.make_camera(vw=16, vh=9), 32, 18, 1)
+    assert torch.cuda.current_device() == 0
+    ds.close()
+    assert torch.cuda.current_device() == 0
+
+
 def test_counters_and_profile(api):
     ds = api.DeviceScene(util.world("box").export())
     cam = api.make_camera(vw=16, vh=9)
