@@ -119,7 +119,8 @@ def run_config(name, cfg, args, steps, warmup, count, rank, local_rank, world, d
     W, H, spp_total = cfg["W"], cfg["H"], cfg["spp"]
     if args.scaling == "strong" and world > 1:
         # the configuration's samples, split: rank r renders indices r, r + world, ...
-        spp = len(range(rank, spp_total, world))
+        from pathtracer_amd import distributed
+        _, spp, _ = distributed.shard(spp_total, rank, world)
     else:
         spp = spp_total
     meshes, mats = cfg["scene"]()
