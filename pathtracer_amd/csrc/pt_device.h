@@ -324,6 +324,7 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, const LdsScene &C, 
   st.sz = st.iz < 0.0f;
   if (mode_wide(MODE)) {
     const uint32_t s3[3] = {st.sx ? 1u : 0u, st.sy ? 1u : 0u, st.sz ? 1u : 0u};
+    st.sx = st.sy = st.sz = false;  // the fast tree's walk addresses its planes by sign (below) and keeps no sign flags
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       st.gn[a] = 2u * a + s3[a];
@@ -364,9 +365,10 @@ __device__ __forceinline__ bool gate_pass(const SceneDev &S, const LdsScene &C, 
   }
   const float nan = __builtin_nanf("");
   const float ix = st.d.x != 0.0f ? st.ix : nan, iy = st.d.y != 0.0f ? st.iy : nan, iz = st.d.z != 0.0f ? st.iz : nan;
-  const float ax = ((st.sx ? g1.x : g0.x) - st.o.x) * ix, bx = ((st.sx ? g0.x : g1.x) - st.o.x) * ix;
-  const float ay = ((st.sy ? g1.y : g0.y) - st.o.y) * iy, by = ((st.sy ? g0.y : g1.y) - st.o.y) * iy;
-  const float az = ((st.sz ? g1.z : g0.z) - st.o.z) * iz, bz = ((st.sz ? g0.z : g1.z) - st.o.z) * iz;
+  const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;  // the swap of object.cpp:186-187
+  const float ax = ((sx ? g1.x : g0.x) - st.o.x) * ix, bx = ((sx ? g0.x : g1.x) - st.o.x) * ix;
+  const float ay = ((sy ? g1.y : g0.y) - st.o.y) * iy, by = ((sy ? g0.y : g1.y) - st.o.y) * iy;
+  const float az = ((sz ? g1.z : g0.z) - st.o.z) * iz, bz = ((sz ? g0.z : g1.z) - st.o.z) * iz;
   const float tn = fmaxf(fmaxf(fmaxf(1e-5f, ax), ay), az);
   const float tf = fminf(fminf(fminf(__builtin_inff(), bx), by), bz);
   return tf >= tn;

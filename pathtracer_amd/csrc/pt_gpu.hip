@@ -60,7 +60,7 @@ static int fail(int code, const std::string &msg) {
 
 struct Workspace {
   size_t cap = 0;
-  float *block = nullptr;  // 2 queues x 13 arrays + 8 hit arrays + 3 radiance arrays
+  float *block = nullptr;  // 2 queues, the hit records and the radiance records
   QueueDev q[2];
   HitDev hit{};
   RadDev rad{};
@@ -272,7 +272,7 @@ static void free_workspace(Workspace &w) {
 // Bytes of the two parts of a workspace for `stride` paths in flight (stride a multiple of 64):
 // the queues, hit and radiance arrays with the compaction tables, and (split shading only) the
 // visibility-ray arrays: 3 floats per vertex, 6 floats + 1 byte per (vertex, light).
-static const size_t kWsArrays = 2 * 13 + 8 + 3;
+static const size_t kWsArrays = (2 * kQueueBytesPerPath + kHitBytesPerPath + kRadBytesPerPath) / sizeof(float);
 static size_t ws_main_bytes(size_t stride) {
   const size_t n_chunks = stride / 64;
   return kWsArrays * stride * sizeof(float) + n_chunks * 12 + (size_t)kScanBlock * 4 + 256 + stride;
@@ -294,14 +294,14 @@ static int carve_workspace(Workspace &w, size_t cap, uint32_t n_lights, bool spl
   for (int k = 0; k < 2; ++k) {
     w.q[k].base = p;
     w.q[k].stride = (uint32_t)stride;
-    p += 13 * stride;
+    p += kQueueBytesPerPath / sizeof(float) * stride;
   }
   w.hit.base = p;
   w.hit.stride = (uint32_t)stride;
-  p += 8 * stride;
+  p += kHitBytesPerPath / sizeof(float) * stride;
   w.rad.base = p;
   w.rad.stride = (uint32_t)stride;
-  p += 3 * stride;
+  p += kRadBytesPerPath / sizeof(float) * stride;
   w.chunk_mask = reinterpret_cast<unsigned long long *>(p);
   w.chunk_base = reinterpret_cast<uint32_t *>(w.chunk_mask + n_chunks);
   w.block_tot = w.chunk_base + n_chunks;

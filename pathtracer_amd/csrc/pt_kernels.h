@@ -20,49 +20,61 @@ static const int kScanBlock = 1024;
 static const int kScanPer = 4;
 static const int kScanSpan = kScanBlock * kScanPer;  // chunks one workgroup of k_scan_local covers
 
-// Structure-of-arrays buffers are handed to the kernels as one base pointer and the distance
-// between consecutive arrays: a kernel argument list of some fifty separate pointers did not fit
-// the scalar registers and the shading kernel spent 13 % of its vector instructions spilling
-// them into vector lanes.
+// Path buffers are arrays of 16-byte records, one record per path and array, handed to the kernels as one
+// base pointer and the distance between consecutive arrays.  A wave reads or writes one array as 64
+// consecutive float4 (1 KiB, fully coalesced, one dwordx4 instruction); thirteen separate float arrays
+// took thirteen dword instructions per path and as many array base addresses, which did not fit the scalar
+// registers: the shading kernel re-read 160 spilled scalars per chunk through v_readlane.
 
-struct QueueDev {  // one live path per index; 13 arrays `stride` floats apart
+struct QueueDev {  // one live path per index: three float4 arrays and one float2 array, `stride` paths apart
   float *base;
   uint32_t stride;
-  __device__ __forceinline__ float *arr(uint32_t k) const { return base + (size_t)k * stride; }
-  __device__ __forceinline__ float *ox() const { return arr(0); }  // ray
-  __device__ __forceinline__ float *oy() const { return arr(1); }
-  __device__ __forceinline__ float *oz() const { return arr(2); }
-  __device__ __forceinline__ float *dx() const { return arr(3); }
-  __device__ __forceinline__ float *dy() const { return arr(4); }
-  __device__ __forceinline__ float *dz() const { return arr(5); }
-  __device__ __forceinline__ float *tx() const { return arr(6); }  // throughput
-  __device__ __forceinline__ float *ty() const { return arr(7); }
-  __device__ __forceinline__ float *tz() const { return arr(8); }
-  __device__ __forceinline__ float *lx() const { return arr(9); }  // radiance gathered so far
-  __device__ __forceinline__ float *ly() const { return arr(10); }
-  __device__ __forceinline__ float *lz() const { return arr(11); }
-  __device__ __forceinline__ uint32_t *id() const { return reinterpret_cast<uint32_t *>(arr(12)); }  // sample_in_batch * P + pixel
+  // A = (o.x, o.y, o.z, id)   B = (d.x, d.y, d.z, -)   C = (T.x, T.y, T.z, L.x)   D = (L.y, L.z)
+  // The closest-hit kernel reads A and B only; the shading kernel reads C and D after its visibility walks.
+  __device__ __forceinline__ float4 *A() const { return reinterpret_cast<float4 *>(base); }
+  __device__ __forceinline__ float4 *B() const { return reinterpret_cast<float4 *>(base) + stride; }
+  __device__ __forceinline__ float4 *C() const { return reinterpret_cast<float4 *>(base) + 2 * (size_t)stride; }
+  __device__ __forceinline__ float2 *D() const { return reinterpret_cast<float2 *>(base + 12 * (size_t)stride); }
+  __device__ __forceinline__ uint32_t id(size_t i) const { return __float_as_uint(base[4 * i + 3]); }
+  __device__ __forceinline__ void load_ray(size_t i, V3 &o, V3 &d, uint32_t &id) const {
+    const float4 a = A()[i], b = B()[i];
+    o = mk(a.x, a.y, a.z);
+    d = mk(b.x, b.y, b.z);
+    id = __float_as_uint(a.w);
+  }
+  __device__ __forceinline__ void load_sums(size_t i, V3 &T, V3 &L) const {
+    const float4 c = C()[i];
+    const float2 e = D()[i];
+    T = mk(c.x, c.y, c.z);
+    L = mk(c.w, e.x, e.y);
+  }
+  __device__ __forceinline__ void store(size_t i, V3 o, V3 d, V3 T, V3 L, uint32_t id) const {
+    A()[i] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
+    B()[i] = make_float4(d.x, d.y, d.z, 0.0f);
+    C()[i] = make_float4(T.x, T.y, T.z, L.x);
+    D()[i] = make_float2(L.y, L.z);
+  }
 };
+static const size_t kQueueBytesPerPath = 56;
 
-struct HitDev {  // closest hit of every queued ray; 8 arrays `stride` floats apart
+struct HitDev {  // closest hit of every queued ray
   float *base;
   uint32_t stride;
-  __device__ __forceinline__ float *arr(uint32_t k) const { return base + (size_t)k * stride; }
-  __device__ __forceinline__ float *t() const { return arr(0); }
-  __device__ __forceinline__ float *nx() const { return arr(1); }  // Triangle::normal() of the hit triangle, un-normalised
-  __device__ __forceinline__ float *ny() const { return arr(2); }
-  __device__ __forceinline__ float *nz() const { return arr(3); }
-  __device__ __forceinline__ uint32_t *mat() const { return reinterpret_cast<uint32_t *>(arr(4)); }
-  __device__ __forceinline__ float *u() const { return arr(5); }   // barycentrics and triangle record of the hit:
-  __device__ __forceinline__ float *v() const { return arr(6); }   // written and read only when the scene has a
-  __device__ __forceinline__ uint32_t *slot() const { return reinterpret_cast<uint32_t *>(arr(7)); }  // textured material
+  // H = (t, n.x, n.y, n.z): n = Triangle::normal() of the hit triangle, un-normalised
+  // M = material id     U = (u, v, triangle record, -): written and read only when the scene has a textured material
+  __device__ __forceinline__ float4 *H() const { return reinterpret_cast<float4 *>(base); }
+  __device__ __forceinline__ uint32_t *M() const { return reinterpret_cast<uint32_t *>(base + 4 * (size_t)stride); }
+  __device__ __forceinline__ float4 *U() const { return reinterpret_cast<float4 *>(base + 8 * (size_t)stride); }
+  __device__ __forceinline__ float t(size_t i) const { return base[4 * i]; }
 };
+static const size_t kHitBytesPerPath = 16 + 16 + 16;  // M's array is padded to 16 bytes per path so that U stays 16-byte aligned
 
-struct RadDev {  // finished radiance per (sample in batch, pixel): r, g, b arrays `stride` floats apart
+struct RadDev {  // finished radiance per (sample in batch, pixel): (r, g, b, -)
   float *base;
   uint32_t stride;
-  __device__ __forceinline__ float *ch(uint32_t k) const { return base + (size_t)k * stride; }
+  __device__ __forceinline__ float4 *R() const { return reinterpret_cast<float4 *>(base); }
 };
+static const size_t kRadBytesPerPath = 16;
 
 // What the per-path kernels need of a frame (the camera part stays in FrameDev for k_raygen).
 struct PathFrame {
@@ -176,11 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameDev F, uint32_t n, Queue
   rng.init(F.seed, p, F.sample0 + s * F.stride);
   V3 o, d;
   camera_ray(F, px, py, rng, o, d);
-  q.ox()[i] = o.x; q.oy()[i] = o.y; q.oz()[i] = o.z;
-  q.dx()[i] = d.x; q.dy()[i] = d.y; q.dz()[i] = d.z;
-  q.tx()[i] = 1.0f; q.ty()[i] = 1.0f; q.tz()[i] = 1.0f;
-  q.lx()[i] = 0.0f; q.ly()[i] = 0.0f; q.lz()[i] = 0.0f;
-  q.id()[i] = i;
+  q.store(i, o, d, mk(1.0f, 1.0f, 1.0f), mk(0.0f, 0.0f, 0.0f), i);
 }
 
 // Camera::point_towards for every pixel, for callers that only want the directions.
@@ -365,7 +373,7 @@ __device__ __forceinline__ bool survives(const SceneDev &S, const PathFrame &F, 
   if (t == __builtin_inff()) return false;
   if (F.max_depth > 0 && depth >= F.max_depth) return false;
   if (depth <= F.rr_min_depth) return true;
-  return survives_id(S, F, depth, q.id()[i], t);
+  return survives_id(S, F, depth, q.id(i), t);
 }
 
 // Closest hit for every queued ray.  The kernel also decides which paths go on after this
@@ -382,20 +390,16 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
   walk_items<MODE, false, COUNT, true, RES, REFILL, BLOCK>(
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
-        o = mk(q.ox()[i], q.oy()[i], q.oz()[i]);
-        d = mk(q.dx()[i], q.dy()[i], q.dz()[i]);
+        uint32_t id;
+        q.load_ray(i, o, d, id);
         return true;
       },
       [&](uint64_t i, const RayState &st) {
         HitRec h = st.best;
         hit_finish<MODE, RES>(S, C, st.o, st.d, h, S.n_tex != 0, true);
-        hit.t()[i] = h.t;
-        hit.nx()[i] = h.n.x; hit.ny()[i] = h.n.y; hit.nz()[i] = h.n.z;
-        hit.mat()[i] = h.mat;
-        if (S.n_tex) {
-          hit.u()[i] = h.u; hit.v()[i] = h.v;
-          hit.slot()[i] = h.slot;
-        }
+        hit.H()[i] = make_float4(h.t, h.n.x, h.n.y, h.n.z);
+        hit.M()[i] = h.mat;
+        if (S.n_tex) hit.U()[i] = make_float4(h.u, h.v, __uint_as_float(h.slot), 0.0f);
         alive_out[i] = survives(S, F, depth, q, (uint32_t)i, h.t) ? 1 : 0;
       });
   if (COUNT) {
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_walk(SceneDev S, LdsPlan plan,
       S, C, stk, (uint64_t)n * S.n_lights, kRun, head, nb, nt,
       [&](uint64_t k, V3 &o, V3 &d) {
         const uint32_t i = (uint32_t)(k % n);
-        if (hit.t()[i] == __builtin_inff()) return false;  // no vertex, no light loop: nobody reads vis[k]
+        if (hit.t(i) == __builtin_inff()) return false;  // no vertex, no light loop: nobody reads vis[k]
         o = mk(sd.x()[i], sd.y()[i], sd.z()[i]);
         d = mk(sd.tx()[k], sd.ty()[k], sd.tz()[k]);
         return true;
@@ -701,22 +705,22 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(0, 0, 0), L = mk(0, 0, 0);
     uint32_t id = 0;
     if (active) {
-      id = in.id()[i];
-      const float t = hit.t()[i];
+      const float4 hr = hit.H()[i];
+      const float t = hr.x;
       if (t == __builtin_inff()) {  // camera.cpp:65-66
+        id = in.id(i);
         if (PHASE != 1) {
-          T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
-          L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
+          in.load_sums(i, T, L);
           L = add(L, mul(T, mk(F.bg[0], F.bg[1], F.bg[2])));
         }
       } else {
         did_hit = true;
         V3 x, nrm;
         {
-          const V3 ro = mk(in.ox()[i], in.oy()[i], in.oz()[i]);
-          const V3 rd = mk(in.dx()[i], in.dy()[i], in.dz()[i]);
+          V3 ro, rd;
+          in.load_ray(i, ro, rd, id);
           x = add(ro, scale(rd, t));                                          // camera.cpp:68
-          nrm = normalize(mk(hit.nx()[i], hit.ny()[i], hit.nz()[i]));         // camera.cpp:69
+          nrm = normalize(mk(hr.y, hr.z, hr.w));                              // camera.cpp:69
           if (dot(nrm, normalize(rd)) > 0.0f) nrm = neg(nrm);                 // camera.cpp:72-73
         }
 
@@ -751,9 +755,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
               local = add(local, mk(sd.wx()[k], sd.wy()[k], sd.wz()[k]));
             }
           }
-          T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
-          L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
-          const uint32_t mat_id = hit.mat()[i];
+          in.load_sums(i, T, L);
+          const uint32_t mat_id = hit.M()[i];
           const float4 *mp = reinterpret_cast<const float4 *>(S.mats + mat_id);
           const float4 m0 = mp[0], m1 = mp[1];
           const V3 ke = mk(m1.x, m1.y, m1.z);
@@ -766,7 +769,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
             uint32_t slot = 0;
             float bu = 0, bv = 0;
             if (TEX && __float_as_uint(m0.w) != 0) {
-              slot = hit.slot()[i]; bu = hit.u()[i]; bv = hit.v()[i];
+              const float4 ur = hit.U()[i];
+              bu = ur.x; bv = ur.y; slot = __float_as_uint(ur.z);
             }
             bounce<MODE, TEX>(S, F, rng, base, nrm, m0, slot, bu, bv, T, w);
             o = x;  // no offset along the normal, camera.cpp:155
@@ -781,13 +785,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
     if (alive) {
       const uint32_t j = block_off[(run + c) / kScanSpan] + chunk_base[run + c] +
                          (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      out.ox()[j] = o.x; out.oy()[j] = o.y; out.oz()[j] = o.z;
-      out.dx()[j] = d.x; out.dy()[j] = d.y; out.dz()[j] = d.z;
-      out.tx()[j] = T.x; out.ty()[j] = T.y; out.tz()[j] = T.z;
-      out.lx()[j] = L.x; out.ly()[j] = L.y; out.lz()[j] = L.z;
-      out.id()[j] = id;
+      out.store(j, o, d, T, L, id);
     } else if (active) {
-      rad.ch(0)[id] = L.x; rad.ch(1)[id] = L.y; rad.ch(2)[id] = L.z;
+      rad.R()[id] = make_float4(L.x, L.y, L.z, 0.0f);
     }
   }
   if (PHASE != 1 && lane == 0 && n_hit) atomicAdd(&cnt[1], n_hit);
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, LdsPlan plan, uint32
     const uint32_t n_idle = 64u - (uint32_t)__popcll(m_alive);
     if ((n_idle >= 8u && (more || pool < pool_end)) || m_alive == 0) {
       if (!alive && mine) {
-        rad.ch(0)[id] = L.x; rad.ch(1)[id] = L.y; rad.ch(2)[id] = L.z;
+        rad.R()[id] = make_float4(L.x, L.y, L.z, 0.0f);
         const uint32_t done = (uint32_t)(depth - depth0);
         if (done > levels) levels = done;
         mine = false;
@@ -844,11 +844,8 @@ __global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, LdsPlan plan, uint32
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         const uint64_t i = pool + rank;
         if (i < pool_end) {
-          o = mk(in.ox()[i], in.oy()[i], in.oz()[i]);
-          d = mk(in.dx()[i], in.dy()[i], in.dz()[i]);
-          T = mk(in.tx()[i], in.ty()[i], in.tz()[i]);
-          L = mk(in.lx()[i], in.ly()[i], in.lz()[i]);
-          id = in.id()[i];
+          in.load_ray(i, o, d, id);
+          in.load_sums(i, T, L);
           depth = depth0;
           alive = true;
           mine = true;
@@ -1004,13 +1001,14 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t n_blocks, uint
 // accum[p] += sum over the batch's samples, in sample order (so the float sum does not
 // depend on how paths were scheduled).
 __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t P, uint32_t S, RadDev rad, float *accum) {
-  const float *Lr = rad.ch(0), *Lg = rad.ch(1), *Lb = rad.ch(2);
+  const float4 *R = rad.R();
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= P) return;
   float r = accum[3 * (size_t)p + 0], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
   for (uint32_t s = 0; s < S; ++s) {
     const size_t k = (size_t)s * P + p;
-    r += Lr[k]; g += Lg[k]; b += Lb[k];
+    const float4 x = R[k];
+    r += x.x; g += x.y; b += x.z;
   }
   accum[3 * (size_t)p + 0] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
 }
