@@ -197,9 +197,10 @@ static int make_plan(PtScene *s, bool wide) {
   }
   if (p.stack > cap) p.stack = cap;
   p.block = p.stack <= 32 ? 1024 : (p.stack <= 64 ? 512 : 256);
+  bool block_given = false;
   if (const char *e = std::getenv("PT_BLOCK")) {  // tuning knob
     const int b = std::atoi(e);
-    if ((b == 256 || b == 512 || b == 1024) && (size_t)p.stack * b * 4 <= 128 * 1024) p.block = b;
+    if ((b == 256 || b == 512 || b == 1024) && (size_t)p.stack * b * 4 <= 128 * 1024) { p.block = b; block_given = true; }
   }
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
@@ -208,34 +209,47 @@ static int make_plan(PtScene *s, bool wide) {
     const int st = std::atoi(e);
     if (st >= 4 && st <= 128 && (size_t)st * p.block * 4 <= 128 * 1024) p.stack = st;
   }
-  const size_t stack_bytes = (size_t)p.stack * p.block * 4;
-  size_t budget = lds_cu - stack_bytes - 512;
-  if (const char *e = std::getenv("PT_LDS_BUDGET_KB")) {
-    const size_t kb = (size_t)std::atol(e) * 1024;
-    if (kb < budget) budget = kb;
-  }
   const size_t node_bytes = (size_t)n_nodes * node_lds;
   const size_t tri_bytes = (size_t)n_tris * sizeof(ptl::TriRec);
-  p.lds.n_gates = 0;
-  if (node_bytes + tri_bytes + gate_bytes <= budget) {
-    p.lds.n_nodes = n_nodes;
-    p.lds.n_tris = n_tris;
-    p.lds.n_gates = wide ? s->dev.n_gates : 0;
-  } else {
-    const size_t fit = budget / node_lds;
-    p.lds.n_nodes = (uint32_t)(fit < n_nodes ? fit : n_nodes);
-    p.lds.n_tris = 0;
+  // lays the LDS of a workgroup out for p.block threads with at most `share` bytes of the CU's LDS
+  auto layout = [&](size_t share) {
+    const size_t stack_bytes = (size_t)p.stack * p.block * 4;
+    size_t budget = share > stack_bytes + 512 ? share - stack_bytes - 512 : 0;
+    if (const char *e = std::getenv("PT_LDS_BUDGET_KB")) {
+      const size_t kb = (size_t)std::atol(e) * 1024;
+      if (kb < budget) budget = kb;
+    }
+    p.lds.n_gates = 0;
+    if (node_bytes + tri_bytes + gate_bytes <= budget) {
+      p.lds.n_nodes = n_nodes;
+      p.lds.n_tris = n_tris;
+      p.lds.n_gates = wide ? s->dev.n_gates : 0;
+    } else {
+      const size_t fit = budget / node_lds;
+      p.lds.n_nodes = (uint32_t)(fit < n_nodes ? fit : n_nodes);
+      p.lds.n_tris = 0;
+    }
+    p.lds_bytes = (size_t)p.lds.n_nodes * node_lds + (size_t)p.lds.n_tris * sizeof(ptl::TriRec) +
+                  (size_t)p.lds.n_gates * sizeof(ptl::GateBox) + stack_bytes;
+    unsigned per_cu = (unsigned)(lds_cu / p.lds_bytes);
+    const unsigned by_threads = 2048u / (unsigned)p.block;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
+    return p.lds.n_nodes == n_nodes && p.lds.n_tris == n_tris && !std::getenv("PT_NO_RESIDENT");
+  };
+  p.resident = layout(lds_cu);
+  if (!p.resident && !block_given && p.stack <= 32) {
+    // A scene outside LDS waits on memory, not on LDS: measured, the staged top of the tree buys nothing
+    // there (160 KiB or 8 KiB of it: the same rate), while a fifth wave per SIMD does for the visibility
+    // walks (64 lights: +11 %).  So: workgroups of 256 threads, and the visibility kernel is compiled to fit
+    // five waves per SIMD at that size.  A sixth of the CU's LDS each: with a fifth (32 KiB) the fifth
+    // workgroup was measured not to become resident.
+    p.block = 256;
+    p.resident = layout(lds_cu / 6);
   }
-  p.lds_bytes = (size_t)p.lds.n_nodes * node_lds + (size_t)p.lds.n_tris * sizeof(ptl::TriRec) +
-                (size_t)p.lds.n_gates * sizeof(ptl::GateBox) + stack_bytes;
-  unsigned per_cu = (unsigned)(lds_cu / p.lds_bytes);
-  const unsigned by_threads = 2048u / (unsigned)p.block;
-  if (per_cu > by_threads) per_cu = by_threads;
-  if (per_cu < 1) per_cu = 1;
-  p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
   p.lds.stack_lds = (uint32_t)p.stack;
   p.lds.spill = nullptr;
-  p.resident = p.lds.n_nodes == n_nodes && p.lds.n_tris == n_tris && !std::getenv("PT_NO_RESIDENT");
   p.split = !p.resident;
   if (const char *e = std::getenv("PT_RES_REFILL")) p.refill_resident = std::atoi(e) != 0;  // tuning knob
   if (const char *e = std::getenv("PT_SPLIT")) p.split = std::atoi(e) != 0;  // tuning knob
