@@ -116,7 +116,8 @@ struct PtScene {
   unsigned long long *h_stats = nullptr;   // pinned
   bool count_stats = false;
   bool profile = false;
-  uint32_t tail_paths = 0;                 // a batch with at most this many live paths is finished by k_tail (0: never)
+  uint32_t tail_paths = 0;                 // PT_TAIL: a batch with at most this many live paths is finished by k_tail (0: never)
+  bool tail_given = false;                 // PT_TAIL was set; otherwise tail_limit() chooses
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   PtProfile prof{};
   // What the launches of the call in progress use: the scene's own workspace and counter block, or
@@ -267,6 +268,17 @@ static int make_plan(PtScene *s, bool wide) {
   p.quorum_any = s->dev.quorum_any;
   if (!p.resident && !std::getenv("PT_QUORUM_ANY")) p.quorum_any = 16;
   return PT_OK;
+}
+
+// Live paths at or below which a batch is handed to the tail kernel.  Measured at 1080p (G rays/s at 16 / 64
+// samples per pixel): the room in LDS 13.9 / 16.8 at 65 536, 15.6 / 17.4 anywhere from 3 M to 16 M; the 7 M
+// triangles outside LDS at 4 / 16 samples 1.96 / 2.97 at 65 536, 2.10 / 3.01 at 1 M, 1.99 / 2.92 at 2 M.
+// The tail kernel walks a vertex's visibility rays one light after the other: with many lights the passes of
+// the wavefront pipeline stay cheaper to the very end (64 lights: 12 ms of tail for 2 000 paths).
+static uint32_t tail_limit(const PtScene *s, int mode) {
+  if (s->tail_given) return s->tail_paths;
+  if (s->dev.n_lights > 4) return 0;
+  return (mode_wide(mode) ? s->plan4 : s->plan).resident ? (4u << 20) : (1u << 20);
 }
 
 // Plan and device view of the scene for a traversal mode.
@@ -735,12 +747,9 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     if (q >= 1 && q <= 64) s->dev.quorum = (uint32_t)q;
   }
   s->max_depth = f.max_depth; s->max_depth4 = f.max_depth4; s->n_meshes = f.n_meshes;
-  // the tail kernel walks a vertex's visibility rays one light after the other: with many lights the passes
-  // of the wavefront pipeline stay cheaper to the very end (terrain with 64 lights: 12 ms of tail for 2 000 paths)
-  s->tail_paths = s->dev.n_lights <= 4 ? 65536u : 0u;
   if (const char *e = std::getenv("PT_TAIL")) {  // tuning knob: 0 switches the tail kernel off
     const long v = std::atol(e);
-    if (v >= 0 && v <= (1l << 30)) s->tail_paths = (uint32_t)v;
+    if (v >= 0 && v <= (1l << 30)) { s->tail_paths = (uint32_t)v; s->tail_given = true; }
   }
   int rc = make_plan(s, false);
   if (rc == PT_OK) rc = make_plan(s, true);
@@ -1039,7 +1048,7 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
       HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), st));
-      if (n <= s->tail_paths) {
+      if (n <= tail_limit(s, o.trace_mode)) {
         // few paths left: one kernel follows each of them to its end
         if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
         rc = with_mode(o.trace_mode, [&](auto MM) -> int {

@@ -266,6 +266,17 @@ __device__ __forceinline__ uint32_t next_run(uint32_t *head, uint32_t len) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
 }
 
+// Length of a wave's next run after it has claimed chunks [run, run + len) of n_chunks: a share of what is left
+// (as far as this wave knows: the head has moved on since), never more than the launch's first run length.
+// Runs of one fixed length leave the waves finishing up to a whole run apart, a quarter of the launch at the
+// lengths the host picks; with shrinking runs they finish within a chunk or two of each other.
+__device__ __forceinline__ uint32_t next_len(uint64_t n_chunks, uint32_t run, uint32_t len, uint32_t first_len, uint32_t waves) {
+  const uint64_t end = (uint64_t)run + len;
+  const uint64_t left = n_chunks > end ? n_chunks - end : 0;
+  const uint64_t share = left / (2ull * waves);
+  return share < 1 ? 1u : (share > first_len ? first_len : (uint32_t)share);
+}
+
 // Walks one ray per work item for items [0, n), persistent over the whole launch.
 //   fetch(i, o, d)  loads item i's ray; returns false when the item needs no walk (it then has
 //                   written whatever the item's output is);
@@ -284,10 +295,15 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
                                            uint32_t *head, uint32_t &nb, uint32_t &nt, Fetch fetch, Retire retire) {
   if constexpr (!REFILL) {
     const uint32_t lane = threadIdx.x & 63;
+    const uint64_t n_chunks = (n + 63u) / 64u;
+    const uint32_t waves = gridDim.x * (BLOCK / 64);
+    uint32_t len = kRun;
     for (;;) {
-      const uint32_t run = next_run(head, kRun);
+      const uint32_t run = next_run(head, len);
       if ((uint64_t)run * 64u >= n) break;
-      for (uint32_t c = 0; c < kRun; ++c) {
+      const uint32_t this_len = len;
+      len = next_len(n_chunks, run, len, kRun, waves);
+      for (uint32_t c = 0; c < this_len; ++c) {
         const uint64_t base = ((uint64_t)run + c) * 64u;
         if (base >= n) break;
         const uint64_t i = base + lane;
@@ -308,6 +324,9 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
     const uint64_t NONE = ~0ull;
     uint64_t mine = NONE;             // item this lane works on or has finished
     bool busy = false;
+    const uint64_t n_chunks = (n + 63u) / 64u;
+    const uint32_t waves = gridDim.x * (BLOCK / 64);
+    uint32_t len = kRun;
     RayState st;
     st.live = false;
     st.pend = 0;
@@ -322,13 +341,14 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
           mine = NONE;
         }
         if (pool >= pool_end && more) {
-          const uint32_t run = next_run(head, kRun);
+          const uint32_t run = next_run(head, len);
           if ((uint64_t)run * 64u >= n) {
             more = false;
           } else {
             pool = (uint64_t)run * 64u;
-            const uint64_t e = ((uint64_t)run + kRun) * 64u;
+            const uint64_t e = ((uint64_t)run + len) * 64u;
             pool_end = e < n ? e : n;
+            len = next_len(n_chunks, run, len, kRun, waves);
           }
         }
         if (!busy) {
@@ -691,9 +711,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
   const int lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0, n_hit = 0;
   uint32_t *head = cnt + (PHASE == 1 ? 4 : 3);
-  for (uint32_t run = next_run(head, kRun), c = 0;; ++c) {
-    if (c == kRun) {
-      run = next_run(head, kRun);
+  const uint32_t n_chunks = (n + 63u) / 64u, waves = gridDim.x * (BLOCK / 64);
+  uint32_t len = kRun;
+  for (uint32_t run = next_run(head, len), c = 0;; ++c) {
+    if (c == len) {
+      len = next_len(n_chunks, run, len, kRun, waves);
+      run = next_run(head, len);
       c = 0;
     }
     const uint32_t first_item = (run + c) * 64u;
@@ -817,6 +840,9 @@ __global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, LdsPlan plan, uint32
   uint64_t pool = 0, pool_end = 0;
   bool more = true;
   bool alive = false, mine = false;
+  const uint64_t n_chunks = ((uint64_t)n + 63u) / 64u;
+  const uint32_t waves = gridDim.x * (BLOCK / 64);
+  uint32_t len = kRun;
   V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(0, 0, 0), L = mk(0, 0, 0);
   uint32_t id = 0;
   int depth = depth0;
@@ -831,13 +857,14 @@ __global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, LdsPlan plan, uint32
         mine = false;
       }
       if (pool >= pool_end && more) {
-        const uint32_t run = next_run(head, kRun);
+        const uint32_t run = next_run(head, len);
         if ((uint64_t)run * 64u >= n) {
           more = false;
         } else {
           pool = (uint64_t)run * 64u;
-          const uint64_t e = ((uint64_t)run + kRun) * 64u;
+          const uint64_t e = ((uint64_t)run + len) * 64u;
           pool_end = e < n ? e : n;
+          len = next_len(n_chunks, run, len, kRun, waves);
         }
       }
       if (!alive) {
