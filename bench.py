@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank renders the full sample count, strong = the sample count is split")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-profile", action="store_true", help="no HIP events around the kernels of the timed steps (kernel times and roofline become null)")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented pass (per-ray work counts become null)")
     ap.add_argument("--max-depth", type=int, default=-1)
     ap.add_argument("--aperture", type=float, default=-1.0)
@@ -160,7 +161,7 @@ def run_config(name, cfg, args, steps, warmup, count, rank, local_rank, world, d
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    ds.profile(True)
+    ds.profile(not args.no_profile)
     ds.read_profile()
     if world > 1:
         dist.barrier()
