@@ -231,16 +231,63 @@ def test_no_device_fails_loudly():
         host.Scene.from_meshes(*scenes.box_room(4)).device_scene(0)
 
 
+@pytest.mark.parametrize("name", ["plane", "box", "box40", "atrium_small", "blob_small", "terrain_small"])
+def test_flattened_scene_and_fast_tree_pass_the_host_check(name):
+    """pt_scene_check needs no device: it flattens the description exactly as pt_scene_upload does (the
+    reference-shaped wide nodes with their tie ranks, the fast mode's own four-child tree, one gate box per
+    lowest internal node of the reference tree) and verifies the fast tree: every node reachable once,
+    child boxes inside their parents', every triangle in exactly one leaf and inside that leaf's box,
+    gate indices in range."""
+    w = util.world(name)
+    info = api.scene_check(w.export())
+    assert info["n_tris"] == w.n_tris
+    assert info["n_wide_nodes"] >= 1 and info["max_depth"] >= 1
+    assert info["n_fast_nodes"] >= 1 and info["fast_max_depth"] >= 1
+    # a leaf holds at most two triangles and a node four children: the tree cannot be smaller than this
+    assert info["n_fast_nodes"] * 4 * 2 >= w.n_tris
+    # the two-triangle plane is a single leaf: no internal node, so no gate
+    assert (0 if name == "plane" else 1) <= info["n_gates"] <= w.n_tris
+    assert info["n_lights"] >= (0 if name == "plane" else 1)
+
+
 def test_flattener_rejects_malformed_trees():
-    """pt_scene_upload validates the description before touching the device... which it needs first;
-    so the malformed cases are exercised on the GPU box (tests/test_gpu_abi.py).  Here: the Python
-    wrapper refuses arrays of the wrong shape."""
-    ds = None
+    """The description is validated on the host before anything is uploaded (the same cases are sent to
+    pt_scene_upload on the GPU box, tests/test_gpu_abi.py), and the Python wrapper refuses arrays of the
+    wrong shape."""
+    good = util.world("box").export()
+
+    def broken(key, edit):
+        e = {k: v.copy() for k, v in good.items()}
+        edit(e[key])
+        return e
+
+    def field(idx, name, val):
+        def f(a):
+            a[name][idx] = val
+        return f
+
+    def item(idx, val):
+        def f(a):
+            a[idx] = val
+        return f
+
+    cases = [
+        broken("blas_nodes", field(0, "index_or_first", 10 ** 6)),     # child index out of range
+        broken("blas_order", item(0, 10 ** 6)),                        # triangle id out of range
+        broken("blas_order", item(1, int(good["blas_order"][0]))),     # a triangle twice, another never
+        broken("tlas_order", item(0, 77)),                             # mesh id out of range
+        broken("mesh_material", item(0, 99)),                          # material out of range
+        broken("blas_nodes", field(1, "index_or_first", 1)),           # node referenced twice / cycle
+    ]
+    for e in cases:
+        with pytest.raises(api.PtError) as ei:
+            api.scene_check(e)
+        assert ei.value.code == -1 and str(ei.value)
+    assert api.scene_check(good)["n_tris"] == util.world("box").n_tris
     with pytest.raises((ValueError, api.PtError)):
-        e = util.world("box").export()
+        e = {k: v.copy() for k, v in good.items()}
         e["tri_verts"] = e["tri_verts"][:-1]
-        ds = api.DeviceScene(e)
-    assert ds is None
+        api.scene_check(e)
 
 
 def test_scene_cache_round_trip_and_rejection(tmp_path):
