@@ -229,16 +229,19 @@ def run_config(name, cfg, args, steps, warmup, count, rank, local_rank, world, d
             roof["achieved"] = traffic / (avg_ms * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         if counts is not None:
-            # algorithmic bytes of the traversal actually run: 32 B per node box tested, 36 B per triangle
-            # tested, 48 B of ray in / hit out per ray.  Most of them are served by LDS (a scene that fits)
-            # or by L2 / Infinity Cache (one that does not), so they are NOT priced against the HBM peak;
-            # they say how much data the walk touches per ray.
+            # algorithmic bytes of the traversal actually run: 28 B per child box tested in the fast tree (a
+            # 112-byte node of four) or 32 B in the reference-shaped tree, 36 B per triangle tested, 53 B of
+            # queue traffic per ray (32 B ray record in, 21 B hit record out).  All but the last are served by
+            # LDS (a scene that fits) or by L2 / Infinity Cache (one that does not), so they are NOT priced
+            # against the HBM peak; they say how much data the walk touches per ray.
             nb, nt, nr = counts.node_boxes, counts.tri_tests, counts.rays_closest
             roof["node_boxes_per_ray"] = nb / max(1, nr)
             roof["tri_tests_per_ray"] = nt / max(1, nr)
             roof["shadow_node_boxes_per_ray"] = counts.shadow_node_boxes / max(1, counts.rays_shadow)
             roof["shadow_tri_tests_per_ray"] = counts.shadow_tri_tests / max(1, counts.rays_shadow)
-            roof["algorithmic_bytes_per_ray"] = (32.0 * nb + 36.0 * nt + 48.0 * nr) / max(1, nr)
+            box_bytes = 28.0 if mode == "fast" else 32.0
+            roof["algorithmic_bytes_per_ray"] = (box_bytes * nb + 36.0 * nt + 53.0 * nr) / max(1, nr)
+            roof["algorithmic_hbm_bytes_per_ray"] = 53.0 if resident else None
         valu = pmc.get("trace_closest_valu_insts_per_launch")
         if valu:
             # what binds a scene that lives in LDS: wave-level vector instructions per second
