@@ -3,7 +3,7 @@ closest-hit kernel (k_trace_queue, the plain instantiation without work counters
 the L2 hit rate, the wave-level vector instructions, the share of LDS cycles lost to bank conflicts and
 the mean number of active lanes per vector instruction; plus fetch / write bytes of every kernel.
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte read requests of wide
-coalesced reads at 64 bytes, so it is doubled (checked in round 1 against the 24 bytes per ray this
+coalesced reads at 64 bytes, so it is doubled (checked against the bytes per ray this
 kernel reads from the ray queue when the scene itself sits in LDS).
 usage: pmc_to_traffic.py <pmc_summary.json> <config> [<pmc_lanes.json>] > profiles/pmc_<config>.json"""
 import json, sys
