@@ -214,6 +214,8 @@ def run_config(name, cfg, args, steps, warmup, count, rank, local_rank, world, d
         # counter passes of this same command kept under profiles/ (pmc_<config>.json).
         avg_ms = prof["trace_ms"] / launches
         pmc = load_pmc(name)
+        if pmc.get("spp") not in (None, spp):
+            pmc = {}  # collected at another sample count: the launches differ in size, per-launch figures do not apply
         traffic = pmc.get("trace_closest_hbm_bytes_per_launch")
         roof = {
             "bound": "hbm", "kernel": "k_trace_queue (closest hit)",

@@ -5,7 +5,7 @@ the mean number of active lanes per vector instruction; plus fetch / write bytes
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte read requests of wide
 coalesced reads at 64 bytes, so it is doubled (checked against the bytes per ray this
 kernel reads from the ray queue when the scene itself sits in LDS).
-usage: pmc_to_traffic.py <pmc_summary.json> <config> [<pmc_lanes.json>] > profiles/pmc_<config>.json"""
+usage: pmc_to_traffic.py <pmc_summary.json> <config> [<pmc_lanes.json> [<spp of the counter runs>]] > profiles/pmc_<config>.json"""
 import json, sys
 
 
@@ -48,4 +48,6 @@ if len(sys.argv) > 3:
     for name, c in json.load(open(sys.argv[3])).items():
         if is_plain_trace(name) and c.get("SQ_ACTIVE_INST_VALU"):
             out["trace_closest_active_lanes"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
+if len(sys.argv) > 4:
+    out["spp"] = int(sys.argv[4])  # bench.py applies per-launch figures only to runs of the same sample count
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
