@@ -263,10 +263,10 @@ static int make_plan(PtScene *s, bool wide) {
     s->bytes += words * sizeof(uint32_t);
     p.lds.spill = p.d_spill;
   }
-  // measured: visibility walks outside LDS do best testing parked leaves at a quarter of the
-  // unfinished lanes (terrain with 64 lights -5 %), those in LDS at half
+  // measured with the fast tree (1080p / 4K frames, G rays/s): visibility walks test their parked leaves
+  // best at half of the unfinished lanes, in LDS and outside (64 lights: 4.7 at an eighth, 4.9 at a
+  // quarter, 5.4 at half, 5.2 at three quarters)
   p.quorum_any = s->dev.quorum_any;
-  if (!p.resident && !std::getenv("PT_QUORUM_ANY")) p.quorum_any = 16;
   return PT_OK;
 }
 
@@ -737,7 +737,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     const int q = std::atoi(e);
     if (q >= 1 && q <= 64) s->dev.quorum_any = (uint32_t)q;
   }
-  s->dev.refill = 8;
+  s->dev.refill = 16;  // idle lanes at which a wave hands out new rays; measured on 7 M / 260 k triangles: 2 -> 2.82 / 5.38, 4 -> 2.96 / 5.71, 8 -> 3.08 / 5.98, 16 -> 3.13 / 6.11, 32 -> 3.07 / 5.98 G rays/s
   if (const char *e = std::getenv("PT_REFILL")) {  // tuning knob
     const int r = std::atoi(e);
     if (r >= 1 && r <= 64) s->dev.refill = (uint32_t)r;
