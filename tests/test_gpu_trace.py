@@ -196,3 +196,79 @@ def test_hits_counter_matches_the_reference_probe():
     tri = ds.trace_closest(o, d)["tri"]
     ds.close()
     assert abs(hits[tri >= 0].mean() - mean) < 0.06 and hits.max() == mx
+
+
+def _awkward_scene():
+    """Geometry a loader can hand over and the reference accepts: two meshes with coincident triangles (exact
+    ties between meshes), zero-area triangles (repeated and collinear vertices), slivers, a triangle a million
+    units across next to ones a millionth across, triangles whose edges lie on the coordinate axes."""
+    from pathtracer_amd import scenes
+    gv, gt = scenes._grid_quad((-1.5, -1.5, 3.0), (3, 0, 0), (0, 3, 0), 6)
+    odd_v = np.array([
+        [0, 0, 2], [0, 0, 2], [0, 0, 2],                      # a point
+        [-1, 0, 2.5], [0, 0, 2.5], [1, 0, 2.5],               # collinear
+        [-1, 1, 2], [1, 1, 2], [0, 1 + 1e-6, 2],              # sliver
+        [-1e6, -1e6, 40], [1e6, -1e6, 40], [0, 1e6, 40],      # huge
+        [1e-6, 0, 1], [0, 1e-6, 1], [-1e-6, -1e-6, 1],        # tiny, on the view axis
+        [0, 0, 1.5], [1, 0, 1.5], [0, 1, 1.5],                # edges on the axes
+        [0, 0, 1.5], [0, -1, 1.5], [-1, 0, 1.5],
+    ], np.float32)
+    odd_t = np.arange(len(odd_v), dtype=np.uint32).reshape(-1, 3)
+    meshes = [(gv, gt, 0), (gv.copy(), gt.copy(), 1), (odd_v, odd_t, 2)]
+    mats = [((0.8, 0.8, 0.8), (0, 0, 0)), ((0.2, 0.8, 0.2), (0, 0, 0)), ((0.5, 0.5, 0.5), (1, 1, 1))]
+    return meshes, mats
+
+
+def test_awkward_geometry_is_bit_exact(api):
+    """Coincident meshes, zero-area triangles, slivers, extreme sizes, axis-aligned edges: rays through
+    vertices and along edges of the grid (ties between neighbours and between the two coincident meshes),
+    straight down the axes and random, in every traversal mode, through both builders."""
+    from pathtracer_amd import host
+    meshes, mats = _awkward_scene()
+    w = O.World.from_meshes(meshes, mats)
+    hs = host.Scene.from_meshes(meshes, mats)
+    gv = meshes[0][0]
+    o_v = np.zeros_like(gv)
+    rng = np.random.default_rng(5)
+    mid = (0.5 * (gv[rng.integers(0, len(gv), 4000)] + gv[rng.integers(0, len(gv), 4000)])).astype(np.float32)
+    sets = {
+        "vertices": (o_v, gv.copy()),
+        "vertices_off_axis": (np.tile(np.float32([0.25, -0.5, 0.125]), (len(gv), 1)), gv - np.float32([0.25, -0.5, 0.125])),
+        "segments": (np.zeros_like(mid), mid),
+        "axes": (np.tile(np.float32([0, 0, 0]), (6, 1)), np.float32([[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, 1, 0], [1, 0, 1], [0, 1, 1]])),
+        "primary": util.primary_rays(O.default_camera(), 96, 96),
+        "random": util.random_rays(20000, 9, (-2, -2, -1), (2, 2, 5)),
+        "axis": util.axis_rays(4000, 10, (-2, -2, -1), (2, 2, 5)),
+    }
+    for ds_label, ds in (("oracle-built", api.DeviceScene(w.export())), ("host-built", hs.device_scene(0))):
+        for label, (o, d) in sets.items():
+            o = np.ascontiguousarray(o, np.float32)
+            d = np.ascontiguousarray(d, np.float32)
+            ref = w.castray(o, d)
+            for mode in (api.PT_TRACE_EXACT, api.PT_TRACE_FAST, api.PT_TRACE_FAST_BINARY):
+                check_equal(ref, ds.trace_closest(o, d, mode), "awkward/%s/%s/mode%d" % (ds_label, label, mode))
+                assert ((ref["tri"] >= 0) == ds.trace_any(o, d, mode)).all(), "awkward/%s/%s any-hit mode %d" % (ds_label, label, mode)
+        if ds_label == "oracle-built":
+            ds.close()
+    assert (w.castray(*[np.ascontiguousarray(a, np.float32) for a in sets["vertices"]])["tri"] >= 0).mean() > 0.9
+    hs.close()
+
+
+def test_awkward_geometry_renders_like_the_oracle(api):
+    """The same scene rendered (its odd mesh is the light: zero-area, huge and tiny triangles in the area
+    table of Polygon::sample, object.cpp:513-523): radiance sums equal the oracle's bit for bit wherever they
+    are finite, and are non-finite in the same pixels."""
+    meshes, mats = _awkward_scene()
+    w = O.World.from_meshes(meshes, mats)
+    ds = api.DeviceScene(w.export())
+    W, H, spp = 96, 96, 4
+    ref, rc = w.render(O.default_camera(), W, H, spp, seed=3, rng=0, form=1)
+    for mode in (api.PT_TRACE_FAST, api.PT_TRACE_EXACT):
+        got, gc = ds.render(api.make_camera(), W, H, spp, seed=3, opt=api.make_options(trace_mode=mode))
+        fin_r, fin_g = np.isfinite(ref).all(-1), np.isfinite(got).all(-1)
+        assert (fin_r == fin_g).all()
+        same = (util.bits(ref) == util.bits(got)).all(-1) | ~fin_r
+        assert 1.0 - same.mean() <= 1e-3, "%d of %d pixels differ" % ((~same).sum(), same.size)
+        assert abs(int(gc.rays_closest) - int(rc.rays_closest)) <= 1e-3 * rc.rays_closest
+        assert gc.paths == rc.paths
+    ds.close()
