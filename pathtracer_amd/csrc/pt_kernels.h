@@ -821,6 +821,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
   }
 }
 
+// Waves per SIMD the tail kernel is compiled for when the scene is outside LDS (256-thread workgroups).  It
+// holds a whole path beside the walk's state, 176 registers uncapped (2 waves); its walks wait on memory, and
+// more waves in flight are worth more than the spills: 7 M triangles at 4 samples per pixel 38.2 ms uncapped,
+// 35.8 ms at 3 waves (168 registers, 36 bytes of scratch), 35.2 ms at 4 (128 registers, 224 bytes).
+#ifndef PT_TAIL_OCC
+#define PT_TAIL_OCC 4
+#endif
 // The tail of a batch: once few paths are left, every pass of the wavefront pipeline costs its fixed
 // price (launches, a pass over mostly empty queues, the slowest ray of the pass) for almost no work.
 // This kernel takes the remaining paths and follows each one to its end, one path per lane: closest
@@ -828,7 +835,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
 // their order are those of k_trace_queue + k_shade, so the radiance is the same bit for bit.
 // cnt[1] += vertices that hit something, cnt[6] += closest-hit rays, cnt[7] = max(depth levels done).
 template <int MODE, int BLOCK, bool COUNT, bool RES, bool TEX>
-__global__ __launch_bounds__(BLOCK) void k_tail(SceneDev S, LdsPlan plan, uint32_t kRun, PathFrame F, int depth0, uint32_t n,
+__global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256) ? PT_TAIL_OCC : 1) void k_tail(SceneDev S, LdsPlan plan, uint32_t kRun, PathFrame F, int depth0, uint32_t n,
                                                 QueueDev in, RadDev rad, uint32_t *cnt, unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
