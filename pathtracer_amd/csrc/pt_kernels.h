@@ -553,9 +553,12 @@ struct ShadowDev {
   __device__ __forceinline__ uint8_t *vis() const { return vis_; }
 };
 
+#ifndef PT_SHADOW_OCC
+#define PT_SHADOW_OCC 5
+#endif
 // Outside LDS in 256-thread workgroups: the register count is capped for five waves per SIMD (96 registers).
 template <int MODE, int BLOCK, bool COUNT, bool RES>
-__global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256) ? 5 : 1) void k_shadow_walk(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, HitDev hit,
+__global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256) ? PT_SHADOW_OCC : 1) void k_shadow_walk(SceneDev S, LdsPlan plan, uint32_t kRun, uint32_t n, HitDev hit,
                                                        ShadowDev sd, uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
