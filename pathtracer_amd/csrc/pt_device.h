@@ -112,6 +112,7 @@ struct SceneDev {
   const ptl::GateBox *gates;
   const float *tri_uv4;
   uint32_t n_nodes4, n_tris4, n_gates;
+  uint32_t n_ill;                 // ill-conditioned triangles in the scene (REF_NOCULL references exist iff > 0)
   float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
   uint32_t quorum;      // lanes of a wave that must hold a parked leaf before triangles are tested (closest hit)
   uint32_t quorum_any;  // any-hit walks: the same in 64ths of the wave's unfinished lanes
@@ -436,18 +437,23 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
                                            uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
   constexpr bool PRUNE = mode_prunes(MODE), WIDE = mode_wide(MODE);
   if (st.live && !(st.cur & ptl::REF_LEAF)) {
-    const float far = (PRUNE && !ANY) ? st.cull : __builtin_inff();
+    float far = (PRUNE && !ANY) ? st.cull : __builtin_inff();
     if constexpr (WIDE) {
+      // A node reached through a REF_NOCULL reference has an ill-conditioned triangle below it, which can
+      // report a hit at any distance: its children are entered whenever the ray passes their boxes, however
+      // far away those begin.  (Scenes without such triangles have no such references.)
+      if (PRUNE && !ANY && S.n_ill != 0u && (st.cur & ptl::REF_NOCULL)) far = __builtin_inff();
+      const uint32_t node = st.cur & ~ptl::REF_NOCULL;
       // four children; this ray's near planes of all four come as one float4 per axis, its far planes too
       float4 nx, fx, ny, fy, nz, fz, rr;
-      if (RES || st.cur < C.n_nodes) {
-        const uint32_t at = C.node_base + st.cur;
+      if (RES || node < C.n_nodes) {
+        const uint32_t at = C.node_base + node;
         nx = lds_f4(at + st.ln[0]); fx = lds_f4(at + st.lf[0]);
         ny = lds_f4(at + st.ln[1]); fy = lds_f4(at + st.lf[1]);
         nz = lds_f4(at + st.ln[2]); fz = lds_f4(at + st.lf[2]);
         rr = lds_f4(at + 6u * C.n_nodes);
       } else {
-        const size_t at = 8u * (size_t)st.cur;
+        const size_t at = 8u * (size_t)node;
         nx = glb_f4(S.nodes4, at + st.gn[0]); fx = glb_f4(S.nodes4, at + st.gf[0]);
         ny = glb_f4(S.nodes4, at + st.gn[1]); fy = glb_f4(S.nodes4, at + st.gf[1]);
         nz = glb_f4(S.nodes4, at + st.gn[2]); fz = glb_f4(S.nodes4, at + st.gf[2]);
@@ -564,7 +570,7 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   if (enough || m_node == 0) {
     if (st.pend != 0) {
       const uint32_t first = st.pend & ptl::REF_FIRST_MASK;
-      const uint32_t cnt = ((st.pend >> 28) & 7u) + 1u;
+      const uint32_t cnt = ((st.pend >> 28) & (WIDE ? 1u : 7u)) + 1u;  // the fast tree's leaves hold one or two
       st.pend = 0;
       const bool in_lds = RES || first + cnt <= C.n_tris;
       const void *gtris = WIDE ? (const void *)S.tris4 : (const void *)S.tris;

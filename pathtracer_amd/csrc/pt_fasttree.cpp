@@ -245,18 +245,29 @@ struct FastBuilder {
   // are the reference's own, tested with the reference's arithmetic: a flat wall keeps its flat box and a ray
   // leaving that wall does not enter it); an inner node's box is the union of its children's.
   std::vector<Box3> tb;
+  std::vector<uint8_t> ill;  // per binary node: an ill-conditioned triangle below it
   void test_boxes() {
     const float margin = out.margin_rel * out.max_abs_coord + 2.0e-5f;
     tb.resize(bn.size());
+    ill.assign(bn.size(), 0);
+    out.n_ill = 0;
     for (size_t i = bn.size(); i-- > 0;) {  // children were created after their parent
       const BinNode &b = bn[i];
       if (b.count == 0) {
         tb[i] = tb[b.left];
         tb[i].grow(tb[b.right]);
+        ill[i] = ill[b.left] | ill[b.right];
         continue;
       }
       Box3 w = b.box;
       for (int k = 0; k < 3; ++k) { w.lo[k] -= margin; w.hi[k] += margin; }
+      for (uint32_t t = 0; t < b.count; ++t)
+        if (triangle_is_ill_conditioned(d.tri_verts + (size_t)out.tris[order[b.first + t]].tri_id * 9)) {
+          // its hits are not bounded by its vertices: nothing tighter than the gate (below)
+          for (int k = 0; k < 3; ++k) { w.lo[k] = -INFINITY; w.hi[k] = INFINITY; }
+          ill[i] = 1;
+          ++out.n_ill;
+        }
       Box3 g;
       g.clear();
       bool all = true;
@@ -363,6 +374,7 @@ struct FastBuilder {
         o.loz[k] = cb.lo[2]; o.hiz[k] = cb.hi[2];
         if (c.count > 0) o.ref[k] = REF_LEAF | ((c.count - 1) << 28) | leaf_first[w.child[k]];
         else o.ref[k] = newidx[wide_of[w.child[k]]];
+        if (ill[w.child[k]]) o.ref[k] |= REF_NOCULL;
       }
     }
 
@@ -377,7 +389,7 @@ struct FastBuilder {
         if (e.second > deepest) deepest = e.second;
         const Quad4Node &o = out.nodes4[e.first];
         for (int k = 0; k < 4; ++k)
-          if (!(o.ref[k] & REF_LEAF)) walk.push_back(std::make_pair(o.ref[k], e.second + 1));
+          if (!(o.ref[k] & REF_LEAF)) walk.push_back(std::make_pair(o.ref[k] & ~REF_NOCULL, e.second + 1));
       }
     }
     out.max_depth4 = 3 * deepest + 2;

@@ -510,6 +510,28 @@ struct Flattener {
 
 // Invariants of the fast tree: every triangle record is referenced by exactly one leaf, every child box
 // contains (with the margin) the boxes or triangles below it, references stay in range.
+bool triangle_is_ill_conditioned(const float *p) {
+  double e1[3], e2[3];
+  for (int k = 0; k < 3; ++k) {
+    e1[k] = (double)p[3 + k] - (double)p[k];
+    e2[k] = (double)p[6 + k] - (double)p[k];
+  }
+  const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+  const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  const double a = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], b = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+  if (!std::isfinite(cc) || !std::isfinite(a) || !std::isfinite(b)) return true;
+  static const double limit = [] {
+    int shift = 9;  // sine of the angle between the edges at v0 below 2^-shift
+    if (const char *e = std::getenv("PT_ILL_SHIFT")) {  // tuning knob; 99: only exactly parallel edges
+      const int v = std::atoi(e);
+      if (v >= 0 && v <= 100) shift = v;
+    }
+    return shift == 100 ? -1.0 : (shift == 99 ? 0.0 : std::ldexp(1.0, -2 * shift));  // 100: no triangle counts (for measurements)
+  }();
+  if (limit < 0) return false;
+  return !(cc > a * b * limit);
+}
+
 int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) {
   const uint32_t n_tris = (uint32_t)f.tris4.size();
   if (f.nodes4.empty() || n_tris == 0 || f.tri_id4.size() != n_tris) {
@@ -517,10 +539,11 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
     return PT_ERR_INVALID;
   }
   std::vector<uint8_t> seen(n_tris, 0), node_seen(f.nodes4.size(), 0);
-  struct Item { uint32_t node; float lo[3], hi[3]; };
+  struct Item { uint32_t node; float lo[3], hi[3]; bool nocull; };
   std::vector<Item> todo;
   Item root;
   root.node = 0;
+  root.nocull = true;  // the root is entered by every ray
   for (int k = 0; k < 3; ++k) { root.lo[k] = -INFINITY; root.hi[k] = INFINITY; }
   todo.push_back(root);
   while (!todo.empty()) {
@@ -534,13 +557,15 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
       if (lo[0] > hi[0]) continue;  // unused slot
       for (int k = 0; k < 3; ++k)
         if (lo[k] < it.lo[k] - 1e-3f || hi[k] > it.hi[k] + 1e-3f) { err = "fast tree: child box outside its parent's"; return PT_ERR_INVALID; }
+      const bool path_nocull = it.nocull && (q.ref[c] & REF_NOCULL) != 0;  // every reference down to here carries the flag
       if (q.ref[c] & REF_LEAF) {
-        const uint32_t first = q.ref[c] & REF_FIRST_MASK, cnt = ((q.ref[c] >> 28) & 7u) + 1u;
+        const uint32_t first = q.ref[c] & REF_FIRST_MASK, cnt = ((q.ref[c] >> 28) & 1u) + 1u;
         if (first + cnt > n_tris - 1) { err = "fast tree: leaf range out of range"; return PT_ERR_INVALID; }
         for (uint32_t t = first; t < first + cnt; ++t) {
           if (seen[t]) { err = "fast tree: triangle in two leaves"; return PT_ERR_INVALID; }
           seen[t] = 1;
           const float *p = d.tri_verts + (size_t)f.tri_id4[t] * 9;
+          if (triangle_is_ill_conditioned(p) && !path_nocull) { err = "fast tree: an ill-conditioned triangle can be skipped by distance"; return PT_ERR_INVALID; }
           for (int v = 0; v < 3; ++v)
             for (int k = 0; k < 3; ++k)
               if (p[3 * v + k] < lo[k] || p[3 * v + k] > hi[k]) { err = "fast tree: triangle outside its leaf box"; return PT_ERR_INVALID; }  // a gate box holds its triangles too
@@ -548,7 +573,8 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
         }
       } else {
         Item ch;
-        ch.node = q.ref[c];
+        ch.node = q.ref[c] & ~REF_NOCULL;
+        ch.nocull = path_nocull;
         for (int k = 0; k < 3; ++k) { ch.lo[k] = lo[k]; ch.hi[k] = hi[k]; }
         todo.push_back(ch);
       }

@@ -22,6 +22,7 @@ struct FlatScene {
   std::vector<LightTri> light_tris;
   // The fast traversal's own tree over the same triangles (see pt_fasttree.cpp)
   std::vector<Quad4Node> nodes4;     // node 0 is the root
+  uint32_t n_ill = 0;                // ill-conditioned triangles in the scene
   std::vector<TriRec4> tris4;        // triangle records in that tree's leaf order, plus the degenerate one at the end
   std::vector<uint32_t> tri_id4;     // per record of tris4: global triangle id in file order (0xffffffff: the degenerate one)
   std::vector<GateBox> gates;        // boxes of the reference's internal nodes
@@ -35,6 +36,17 @@ struct FlatScene {
 };
 
 // Builds nodes4 / tris4 / gate4 / tri_uv4 from tris, tri_gate and the description's vertices.
+// A triangle (nine floats: v0, v1, v2) whose hit test can report hits away from the triangle itself: the
+// reference's test (object.cpp:406-429) divides by e1 . (d x e2); when e1 and e2 are parallel, or nearly (the
+// sine of their angle below 2^-9: from there on the error of the computed hit, about 2^-24 of its distance
+// divided by that sine, outgrows the margin the fast tree's leaf boxes carry), or not finite, that determinant is rounding noise for every ray, and u, v, t
+// come out anywhere, inside [0, 1] often enough to count as a hit far from the triangle's bounds (measured: a
+// zero-area triangle "hit" 12 units away from itself).  The reference reports such hits.  A traversal that
+// prunes by the triangle's bounds or by distance would lose them, so the fast tree bounds these triangles by
+// their gate alone and never skips them for being far (REF_NOCULL), and the pruning walk of the
+// reference-shaped tree is not used on a scene that has any.
+bool triangle_is_ill_conditioned(const float *p9);
+
 void build_fast_tree(const PtSceneDesc &d, FlatScene &out);
 
 // Verifies the invariants of the fast tree (used by pt_scene_check).

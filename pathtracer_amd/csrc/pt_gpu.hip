@@ -565,6 +565,12 @@ static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *o
 
 // Calls f(M) with the traversal mode as an integral constant.
 static bool valid_mode(int mode) { return mode == PT_TRACE_EXACT || mode == PT_TRACE_FAST || mode == PT_TRACE_FAST_BINARY; }
+// The pruning walk of the reference-shaped tree skips leaves by their bounds and by distance; an
+// ill-conditioned triangle can report a hit outside both (triangle_is_ill_conditioned), so a scene that has
+// one is walked exactly instead.  (The fast tree deals with such triangles itself.)
+static int effective_mode(const PtScene *s, int mode) {
+  return (mode == PT_TRACE_FAST_BINARY && s->dev.n_ill != 0) ? PT_TRACE_EXACT : mode;
+}
 template <typename F>
 static int with_mode(int mode, F &&f) {
   switch (mode) {
@@ -730,6 +736,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.nodes4 = s->d_nodes4; s->dev.tris4 = s->d_tris4; s->dev.tri_id4 = s->d_tri_id4; s->dev.gates = s->d_gates;
   s->dev.tri_uv4 = s->d_tri_uv4;
   s->dev.n_nodes4 = (uint32_t)f.nodes4.size(); s->dev.n_tris4 = (uint32_t)f.tris4.size(); s->dev.n_gates = (uint32_t)f.gates.size();
+  s->dev.n_ill = f.n_ill;
   s->dev.margin = f.max_abs_coord * (1.0f / 2048.0f) + 2.0e-5f;
   s->dev.quorum = 32;
   s->dev.quorum_any = 32;
@@ -835,6 +842,7 @@ static int trace_dev(PtScene *s, size_t n, const float *ox, const float *oy, con
   if (n == 0) return PT_OK;
   if (n > ((size_t)1 << 36)) return fail(PT_ERR_INVALID, "too many rays for one call");  // the work-queue head counts chunks of 64 in 32 bits
   if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
+  mode = effective_mode(s, mode);
   int rc = enter_stream(s, st);
   if (rc != PT_OK) return rc;
   rc = with_mode(mode, [&](auto MM) -> int {
@@ -900,6 +908,7 @@ int pt_trace_closest(PtScene *s, size_t n, const float *ox, const float *oy, con
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !t || !tri)) return fail(PT_ERR_INVALID, "null ray or result array");
   if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
+  mode = effective_mode(s, mode);
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
@@ -933,6 +942,7 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hit)) return fail(PT_ERR_INVALID, "null ray or result array");
   if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
+  mode = effective_mode(s, mode);
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
@@ -967,6 +977,7 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
   if (!s) return fail(PT_ERR_INVALID, "null scene");
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !hits)) return fail(PT_ERR_INVALID, "null ray or result array");
   if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
+  mode = effective_mode(s, mode);
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   const size_t chunk = (size_t)1 << 24;
@@ -985,7 +996,7 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
     if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
     int32_t *dh = reinterpret_cast<int32_t *>(buf + 6 * m);
     // HitData::hits is a property of the reference's trees: both pruning modes walk those
-    rc = mode == PT_TRACE_EXACT ? launch_hits_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0)
+    rc = (mode == PT_TRACE_EXACT || s->dev.n_ill != 0) ? launch_hits_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0)
                                 : launch_hits_api<PT_TRACE_FAST_BINARY>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
     if (rc != PT_OK) break;
     e = hipDeviceSynchronize();
@@ -1133,6 +1144,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
   PtOptions o;
   if (opt) o = *opt; else pt_options_default(&o);
   if (!valid_mode(o.trace_mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
+  o.trace_mode = effective_mode(s, o.trace_mode);
   const bool split = plan_of(s, o.trace_mode).split;
   PtCounters c;
   memset(&c, 0, sizeof(c));

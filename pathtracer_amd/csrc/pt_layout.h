@@ -47,6 +47,11 @@ static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 // ray direction on that axis, so a lane addresses piece 2*axis + sign instead of selecting afterwards).
 // As eight float4 "pieces": 0 lo.x[4], 1 hi.x[4], 2 lo.y[4], 3 hi.y[4], 4 lo.z[4], 5 hi.z[4], 6 ref[4], 7 unused.
 // An unused child slot has an inverted box (lo = +inf, hi = -inf) that no ray enters.
+// A child reference with REF_NOCULL set leads to an ill-conditioned triangle (triangle_is_ill_conditioned):
+// that child is entered whenever the ray passes its box, however far away the box begins, because such a
+// triangle can report a hit at any distance.  (Leaves of this tree hold one or two triangles, so of the three
+// count bits of a leaf reference only the lowest is in use.)
+static const uint32_t REF_NOCULL = 0x40000000u;
 struct alignas(16) Quad4Node {
   float lox[4], hix[4], loy[4], hiy[4], loz[4], hiz[4];
   uint32_t ref[4];

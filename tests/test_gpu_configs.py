@@ -1,7 +1,7 @@
 """The named benchmark configurations at their REAL scene sizes, against the oracle.
 
   config 3  atrium260k   259 562 triangles, 18 meshes, 1 light; 5 bounces, thin lens on
-  config 4  blob7m       7 002 284 triangles (the 7 M-triangle blob, deep tree, inside the 1 002-triangle room), 1 light
+  config 4  blob7m       6 998 542 triangles (the 7 M-triangle blob, deep tree, inside the 1 002-triangle room), 1 light
   config 5  terrain1m    999 826 triangles, 65 meshes, 64 area lights (a real top-level tree)
 
 For each: closest hits (t, u, v bit patterns + triangle id) and any-hit answers of the HIP walk equal

@@ -272,3 +272,46 @@ def test_awkward_geometry_renders_like_the_oracle(api):
         assert abs(int(gc.rays_closest) - int(rc.rays_closest)) <= 1e-3 * rc.rays_closest
         assert gc.paths == rc.paths
     ds.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_triangle_soups_bit_exact(api, seed):
+    """Seeded triangle soups of random size, scale and mesh count (some triangles repeated in another mesh,
+    some collapsed to a line, some with vertices snapped to a coarse grid so that edges and whole triangles
+    coincide): closest hit and any hit of every traversal mode equal the oracle's on random rays, on rays
+    aimed at vertices and on rays along the axes."""
+    rng = np.random.default_rng(1000 + seed)
+    n_mesh = int(rng.integers(1, 9))
+    scale = float(10.0 ** rng.integers(-2, 3))
+    meshes, mats = [], []
+    for m in range(n_mesh):
+        nt = int(rng.integers(1, 400))
+        c = rng.uniform(-1, 1, (nt, 1, 3))
+        v = (c + rng.normal(0, rng.uniform(0.02, 0.5), (nt, 3, 3))) * scale
+        if rng.random() < 0.5:
+            v = np.round(v / (0.125 * scale)) * (0.125 * scale)       # coincident vertices, edges, triangles
+        k = rng.random(nt) < 0.05
+        v[k, 2] = v[k, 1]                                             # zero area
+        if m > 0 and rng.random() < 0.5:
+            prev = meshes[int(rng.integers(0, m))][0].reshape(-1, 3, 3)
+            v[: min(nt, len(prev))] = prev[: min(nt, len(prev))]     # the same triangles in two meshes
+        v = np.ascontiguousarray(v.reshape(-1, 3), np.float32)
+        meshes.append((v, np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3), m))
+        mats.append(((0.5, 0.5, 0.5), (0, 0, 0)))
+    w = O.World.from_meshes(meshes, mats)
+    ds = api.DeviceScene(w.export())
+    allv = np.concatenate([m[0] for m in meshes])
+    n = 20000
+    o = (rng.uniform(-2, 2, (n, 3)) * scale).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    tgt = allv[rng.integers(0, len(allv), n)]
+    sets = {"random": (o, d), "at_vertices": (o, (tgt - o).astype(np.float32)),
+            "axes": util.axis_rays(3000, seed, tuple([-2 * scale] * 3), tuple([2 * scale] * 3))}
+    for label, (ro, rd) in sets.items():
+        ro = np.ascontiguousarray(ro, np.float32)
+        rd = np.ascontiguousarray(rd, np.float32)
+        ref = w.castray(ro, rd)
+        for mode in (api.PT_TRACE_EXACT, api.PT_TRACE_FAST, api.PT_TRACE_FAST_BINARY):
+            check_equal(ref, ds.trace_closest(ro, rd, mode), "soup%d/%s/mode%d" % (seed, label, mode))
+            assert ((ref["tri"] >= 0) == ds.trace_any(ro, rd, mode)).all(), "soup%d/%s any-hit mode %d" % (seed, label, mode)
+    ds.close()
