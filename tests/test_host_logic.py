@@ -250,6 +250,28 @@ def test_flattened_scene_and_fast_tree_pass_the_host_check(name):
     assert info["n_lights"] >= (0 if name == "plane" else 1)
 
 
+def test_fast_tree_keeps_ill_conditioned_triangles_reachable():
+    """A zero-area or needle-angled triangle can report a hit far from its own bounds (its determinant is
+    rounding noise), and the reference reports such hits.  The host check walks the fast tree and fails if
+    such a triangle sits behind a reference that may be skipped by distance; here a soup with both kinds,
+    coincident copies and a huge triangle passes it, and so does a scene made of nothing else."""
+    rng = np.random.default_rng(3)
+    nt = 300
+    v = rng.uniform(-1, 1, (nt, 1, 3)) + rng.normal(0, 0.2, (nt, 3, 3))
+    v[::7, 2] = v[::7, 1]                                   # two identical vertices: zero area
+    v[3::11, 2] = v[3::11, 0] + (v[3::11, 1] - v[3::11, 0]) * 2.0 + 1e-7   # collinear up to rounding
+    v[5] = [[-1e5, -1e5, 9], [1e5, -1e5, 9], [0, 1e5, 9]]
+    v = np.ascontiguousarray(v.reshape(-1, 3), np.float32)
+    soup = [(v, np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3), 0)]
+    mats = [((0.5, 0.5, 0.5), (0, 0, 0))]
+    w = O.World.from_meshes(soup, mats)
+    info = api.scene_check(w.export())
+    assert info["n_tris"] == nt
+    only = np.float32([[0, 0, 0], [1, 1, 1], [1, 1, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1]])
+    w2 = O.World.from_meshes([(only, np.uint32([[0, 1, 2], [3, 4, 5]]), 0)], mats)
+    assert api.scene_check(w2.export())["n_tris"] == 2
+
+
 def test_flattener_rejects_malformed_trees():
     """The description is validated on the host before anything is uploaded (the same cases are sent to
     pt_scene_upload on the GPU box, tests/test_gpu_abi.py), and the Python wrapper refuses arrays of the
