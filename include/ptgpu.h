@@ -131,7 +131,12 @@ enum { PT_SAMPLE_UNIFORM = 0, PT_SAMPLE_COSINE = 1 };
  * PT_TRACE_FAST returns the same hits from a tree of its own (four children per node, surface-area
  * heuristic), pruned by distance; a hit counts only if the ray passes the reference's box tests above
  * that triangle.  PT_TRACE_FAST_BINARY is the pruned walk over the reference-shaped trees, kept for
- * comparison. */
+ * comparison (on a scene with an ill-conditioned triangle it is the exact walk).
+ * The pruning modes skip boxes with a margin of 2^-16 of the scene's largest coordinate; the rounding error of
+ * a box test grows with the distance of the ray's origin, so they return the reference's hits for origins
+ * within 16 times that coordinate of the world origin (measured: no mismatch in 600 000 rays at 10 times, the
+ * first at 100 times).  pt_render and pt_render_dev switch to PT_TRACE_EXACT by themselves when the camera
+ * stands farther away; callers of the ray queries with such origins pass PT_TRACE_EXACT. */
 enum { PT_TRACE_EXACT = 0, PT_TRACE_FAST = 1, PT_TRACE_FAST_BINARY = 2 };
 
 /* Integrator constants.  pt_options_default() fills in the reference literals

@@ -106,6 +106,7 @@ struct PtScene {
   ptl::GateBox *d_gates = nullptr;
   float *d_tri_uv4 = nullptr;
   uint32_t max_depth = 0, max_depth4 = 0, n_meshes = 0;
+  float max_abs_coord = 0;                 // largest finite vertex coordinate
   uint64_t bytes = 0;
   Plan plan;                               // launches over the reference-shaped tree (exact mode, fast-binary mode)
   Plan plan4;                              // launches over the fast tree
@@ -738,6 +739,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.n_nodes4 = (uint32_t)f.nodes4.size(); s->dev.n_tris4 = (uint32_t)f.tris4.size(); s->dev.n_gates = (uint32_t)f.gates.size();
   s->dev.n_ill = f.n_ill;
   s->dev.margin = f.max_abs_coord * (1.0f / 2048.0f) + 2.0e-5f;
+  s->max_abs_coord = f.max_abs_coord;
   s->dev.quorum = 32;
   s->dev.quorum_any = 32;
   if (const char *e = std::getenv("PT_QUORUM_ANY")) {  // tuning knob
@@ -1145,6 +1147,13 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
   if (opt) o = *opt; else pt_options_default(&o);
   if (!valid_mode(o.trace_mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   o.trace_mode = effective_mode(s, o.trace_mode);
+  if (o.trace_mode != PT_TRACE_EXACT && cam) {
+    // the margins of the pruning walks cover ray origins up to 16 times the scene's largest coordinate;
+    // every path of a frame starts at the camera (its later vertices lie on the scene)
+    float far = 0;
+    for (int k = 0; k < 3; ++k) far = std::fmax(far, std::fabs(cam->origin[k]));
+    if (!(far <= 16.0f * s->max_abs_coord)) o.trace_mode = PT_TRACE_EXACT;
+  }
   const bool split = plan_of(s, o.trace_mode).split;
   PtCounters c;
   memset(&c, 0, sizeof(c));

@@ -279,3 +279,14 @@ def test_larger_frame_matches_oracle_bitwise(api, name, cam_kw):
     ref, rc, got, gc = both(api, name, 640, 360, 4, cam_kw=cam_kw, seed=7)
     assert_images_match(ref, got, max_diff_frac=1e-4)
     assert gc.rays_closest == rc.rays_closest and gc.rays_shadow == rc.rays_shadow
+
+
+def test_camera_far_from_the_scene_still_matches_the_oracle(api):
+    """A box test's rounding error grows with the distance of the ray's origin; the pruning walks carry a
+    margin for origins near the scene only, so a render whose camera stands farther away than 16 times the
+    scene's largest coordinate runs the exact walk by itself.  Camera 5 000 units in front of the room's open
+    side with a field of view that just frames it: radiance sums equal the oracle's."""
+    kw = dict(origin=(0.0, 0.0, -5000.0), fov=0.06, vw=16, vh=9)
+    ref, rc, got, gc = both(api, "box", 96, 54, 4, cam_kw=kw, opt_kw=dict(trace_mode=api.PT_TRACE_FAST))
+    assert_images_match(ref, got)
+    assert rc.rays_shadow > 0 and abs(gc.rays_closest - rc.rays_closest) <= 2e-3 * rc.rays_closest

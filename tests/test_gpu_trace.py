@@ -274,12 +274,7 @@ def test_awkward_geometry_renders_like_the_oracle(api):
     ds.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
-def test_random_triangle_soups_bit_exact(api, seed):
-    """Seeded triangle soups of random size, scale and mesh count (some triangles repeated in another mesh,
-    some collapsed to a line, some with vertices snapped to a coarse grid so that edges and whole triangles
-    coincide): closest hit and any hit of every traversal mode equal the oracle's on random rays, on rays
-    aimed at vertices and on rays along the axes."""
+def _soup(seed):
     rng = np.random.default_rng(1000 + seed)
     n_mesh = int(rng.integers(1, 9))
     scale = float(10.0 ** rng.integers(-2, 3))
@@ -297,7 +292,38 @@ def test_random_triangle_soups_bit_exact(api, seed):
             v[: min(nt, len(prev))] = prev[: min(nt, len(prev))]     # the same triangles in two meshes
         v = np.ascontiguousarray(v.reshape(-1, 3), np.float32)
         meshes.append((v, np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3), m))
-        mats.append(((0.5, 0.5, 0.5), (0, 0, 0)))
+        mats.append(((0.5, 0.5, 0.5), (2.0, 2.0, 2.0) if m == 0 else (0, 0, 0)))   # the first mesh glows
+    return rng, scale, meshes, mats
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_triangle_soups_render_like_the_oracle(api, seed):
+    """The same soups rendered from inside (mesh 0 is the light, with its share of zero-area triangles in
+    the area table): radiance sums equal the oracle's bit for bit wherever they are finite, non-finite in the
+    same pixels, in fast and in exact traversal."""
+    rng, scale, meshes, mats = _soup(seed)
+    w = O.World.from_meshes(meshes, mats)
+    ds = api.DeviceScene(w.export())
+    W, H, spp = 64, 64, 4
+    cam = dict(origin=(0.1 * scale, -0.05 * scale, -1.5 * scale))
+    ref, rc = w.render(O.default_camera(**cam), W, H, spp, seed=seed, rng=0, form=1)
+    for mode in (api.PT_TRACE_FAST, api.PT_TRACE_EXACT):
+        got, gc = ds.render(api.make_camera(**cam), W, H, spp, seed=seed, opt=api.make_options(trace_mode=mode))
+        fin_r, fin_g = np.isfinite(ref).all(-1), np.isfinite(got).all(-1)
+        assert (fin_r == fin_g).all()
+        same = (util.bits(ref) == util.bits(got)).all(-1) | ~fin_r
+        assert 1.0 - same.mean() <= 2e-3, "soup %d mode %d: %d of %d pixels differ" % (seed, mode, (~same).sum(), same.size)
+        assert abs(int(gc.rays_closest) - int(rc.rays_closest)) <= 2e-3 * rc.rays_closest + 2
+    ds.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_triangle_soups_bit_exact(api, seed):
+    """Seeded triangle soups of random size, scale and mesh count (some triangles repeated in another mesh,
+    some collapsed to a line, some with vertices snapped to a coarse grid so that edges and whole triangles
+    coincide): closest hit and any hit of every traversal mode equal the oracle's on random rays, on rays
+    aimed at vertices and on rays along the axes."""
+    rng, scale, meshes, mats = _soup(seed)
     w = O.World.from_meshes(meshes, mats)
     ds = api.DeviceScene(w.export())
     allv = np.concatenate([m[0] for m in meshes])
