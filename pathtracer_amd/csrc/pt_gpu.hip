@@ -111,7 +111,7 @@ struct PtScene {
   Plan plan;                               // launches over the reference-shaped tree (exact mode, fast-binary mode)
   Plan plan4;                              // launches over the fast tree
   Workspace ws;
-  uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, work-queue heads of trace, shade, shade phase 1, visibility walk
+  uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, work-queue heads of trace [2], fused shade [3], visibility walk [5]
   unsigned long long *d_stats = nullptr;   // node boxes, triangle tests: closest [0,1], visibility [2,3]
   uint32_t *h_cnt = nullptr;               // pinned
   unsigned long long *h_stats = nullptr;   // pinned
@@ -273,7 +273,8 @@ static int make_plan(PtScene *s, bool wide) {
 
 // Live paths at or below which a batch is handed to the tail kernel.  Measured at 1080p (G rays/s at 16 / 64
 // samples per pixel): the room in LDS 13.9 / 16.8 at 65 536, 15.6 / 17.4 anywhere from 3 M to 16 M; the 7 M
-// triangles outside LDS at 4 / 16 samples 1.96 / 2.97 at 65 536, 2.10 / 3.01 at 1 M, 1.99 / 2.92 at 2 M.
+// triangles outside LDS at 4 / 16 samples 2.56 / 3.49 at 128 Ki, 2.65 / 3.55 at 512 Ki, 2.72 / 3.58 at 1 Mi,
+// 2.67 / 3.55 at 2 Mi.
 // The tail kernel walks a vertex's visibility rays one light after the other: with many lights the passes of
 // the wavefront pipeline stay cheaper to the very end (64 lights: 12 ms of tail for 2 000 paths).
 static uint32_t tail_limit(const PtScene *s, int mode) {

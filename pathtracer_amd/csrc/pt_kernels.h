@@ -695,7 +695,7 @@ __device__ __forceinline__ void bounce(const SceneDev &S, const PathFrame &F, Pa
 // The compaction is stable: the queue stays in pixel order and no two launches differ.
 // Claiming an output slot per wave with an atomic on one counter instead was measured at
 // 260 ms per frame on its own: a single word takes under 100 atomics per microsecond.
-// cnt[1] = paths that hit something, cnt[3] / cnt[4] = this kernel's work-queue head (phase 1: cnt[4]).
+// cnt[1] = paths that hit something, cnt[3] = this kernel's work-queue head (PHASE 0).
 //
 // PHASE 0: the whole vertex in one kernel, visibility rays walked in place (scenes in LDS).
 // PHASE 1 / 2 (scenes outside LDS): 1 prepares the visibility rays of every vertex and light
@@ -713,13 +713,24 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
   if constexpr (PHASE == 0) C = stage_scene<BLOCK, MODE>(S, plan, stk);
   const int lane = threadIdx.x & 63;
   uint32_t nb = 0, nt = 0, n_hit = 0;
-  uint32_t *head = cnt + (PHASE == 1 ? 4 : 3);
+  uint32_t *head = cnt + 3;
   const uint32_t n_chunks = (n + 63u) / 64u, waves = gridDim.x * (BLOCK / 64);
-  uint32_t len = kRun;
-  for (uint32_t run = next_run(head, len), c = 0;; ++c) {
+  // PHASE 0 walks visibility rays, so its chunks differ in cost and are claimed from the work queue.  PHASE 1
+  // and 2 stream: every chunk costs about the same, and wave w simply takes chunks w, w + waves, ...  (claimed
+  // from the one queue head they were bound by its atomic, 0.5 ms a launch whatever the number of paths).
+  uint32_t len = PHASE == 0 ? kRun : 1u;
+  uint32_t run;
+  if constexpr (PHASE == 0) run = next_run(head, len);
+  else run = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
+  for (uint32_t c = 0;; ++c) {
     if (c == len) {
-      len = next_len(n_chunks, run, len, kRun, waves);
-      run = next_run(head, len);
+      if constexpr (PHASE == 0) {
+        len = next_len(n_chunks, run, len, kRun, waves);
+        run = next_run(head, len);
+      } else {
+        if (run >= n_chunks - (n_chunks < waves ? n_chunks : waves)) break;  // run + waves would pass the end (or wrap)
+        run += waves;
+      }
       c = 0;
     }
     const uint32_t first_item = (run + c) * 64u;

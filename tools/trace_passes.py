@@ -21,3 +21,13 @@ for r in rows:
 print(" ".join(line))
 print({k: round(v / 1e3, 2) for k, v in tot.items()})
 print("span ms", (int(rows[-1]["End_Timestamp"]) - t0) / 1e6)
+# time with no kernel running between the first start and the last end, and its share after k_shade / k_tail
+# launches (the places where the host waits for a count before it launches again)
+idle = 0.0; after_sync = 0.0; end = int(rows[0]["End_Timestamp"])
+for prev, r in zip(rows, rows[1:]):
+    gap = int(r["Start_Timestamp"]) - end
+    if gap > 0:
+        idle += gap
+        if short(prev["Kernel_Name"]) in ("k_shade", "k_tail", "k_resolve"): after_sync += gap
+    end = max(end, int(r["End_Timestamp"]))
+print("idle ms %.3f, of which after a kernel the host waits for %.3f" % (idle / 1e6, after_sync / 1e6))
