@@ -102,9 +102,9 @@ def test_reduced_frame_of_the_full_scene_matches_the_oracle_bitwise(api, cfg):
     got, gc = ds.render(api.make_camera(**S["cam"]), W, H, spp, seed=17, opt=api.make_options(**S["opt"]))
     assert np.isfinite(got).all() == np.isfinite(ref).all()
     same = (util.bits(ref) == util.bits(got)).all(-1)
-    assert 1.0 - same.mean() <= 1e-3, "%s: %d of %d pixels differ" % (name, (~same).sum(), same.size)
-    assert abs(int(gc.rays_closest) - int(rc.rays_closest)) <= 1e-3 * rc.rays_closest
-    assert abs(int(gc.rays_shadow) - int(rc.rays_shadow)) <= 1e-3 * max(1, rc.rays_shadow)
+    print("%s: %d of %d pixels differ from the oracle" % (name, (~same).sum(), same.size))  # shown with -s / -rP
+    assert same.all(), "%s: %d of %d pixels differ" % (name, (~same).sum(), same.size)
+    assert int(gc.rays_closest) == int(rc.rays_closest) and int(gc.rays_shadow) == int(rc.rays_shadow)
     assert gc.paths == rc.paths == W * H * spp
     assert got.sum() > 0
     if S["opt"].get("max_depth"):

@@ -75,12 +75,12 @@ def test_closest_fast_mode_primary_and_random_bit_exact(api, name):
 @pytest.mark.parametrize("name", [s for s in SCENES if s != "plane"])
 def test_closest_fast_mode_surface_rays(api, name):
     """Rays leaving a surface at grazing angles are ill-conditioned: the reference's own t is
-    noise there.  The fast mode's slack must still keep disagreements below 1 in 10 000."""
+    noise there.  The fast mode's margins must still reproduce it on every ray."""
     w, ds = util.world(name), dev_scene(api, name)
     o, d = ray_sets(name)["surface"]
     ref, got = w.castray(o, d), ds.trace_closest(o, d, api.PT_TRACE_FAST)
     bad = (util.bits(ref["t"]) != util.bits(got["t"])) | (ref["tri"] != got["tri"])
-    assert bad.mean() <= 1e-4, "%s: %d of %d surface rays differ" % (name, bad.sum(), len(bad))
+    assert not bad.any(), "%s: %d of %d surface rays differ" % (name, bad.sum(), len(bad))
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -91,8 +91,7 @@ def test_any_hit_matches_castray(api, name, mode):
         ref = w.castray(o, d)["tri"] >= 0
         got = ds.trace_any(o, d, mode)
         bad = ref != got
-        limit = 1e-4 if (mode == 1 and label == "surface") else 0.0
-        assert bad.mean() <= limit, "%s/%s mode %d: %d of %d differ" % (name, label, mode, bad.sum(), len(bad))
+        assert not bad.any(), "%s/%s mode %d: %d of %d differ" % (name, label, mode, bad.sum(), len(bad))
 
 
 def test_known_answer_rays_plane(api):
@@ -268,8 +267,9 @@ def test_awkward_geometry_renders_like_the_oracle(api):
         fin_r, fin_g = np.isfinite(ref).all(-1), np.isfinite(got).all(-1)
         assert (fin_r == fin_g).all()
         same = (util.bits(ref) == util.bits(got)).all(-1) | ~fin_r
-        assert 1.0 - same.mean() <= 1e-3, "%d of %d pixels differ" % ((~same).sum(), same.size)
-        assert abs(int(gc.rays_closest) - int(rc.rays_closest)) <= 1e-3 * rc.rays_closest
+        print("awkward scene, mode %d: %d of %d pixels differ from the oracle" % (mode, (~same).sum(), same.size))
+        assert same.all(), "%d of %d pixels differ" % ((~same).sum(), same.size)
+        assert int(gc.rays_closest) == int(rc.rays_closest)
         assert gc.paths == rc.paths
     ds.close()
 
@@ -312,8 +312,9 @@ def test_random_triangle_soups_render_like_the_oracle(api, seed):
         fin_r, fin_g = np.isfinite(ref).all(-1), np.isfinite(got).all(-1)
         assert (fin_r == fin_g).all()
         same = (util.bits(ref) == util.bits(got)).all(-1) | ~fin_r
-        assert 1.0 - same.mean() <= 2e-3, "soup %d mode %d: %d of %d pixels differ" % (seed, mode, (~same).sum(), same.size)
-        assert abs(int(gc.rays_closest) - int(rc.rays_closest)) <= 2e-3 * rc.rays_closest + 2
+        print("soup %d, mode %d: %d of %d pixels differ from the oracle" % (seed, mode, (~same).sum(), same.size))
+        assert same.all(), "soup %d mode %d: %d of %d pixels differ" % (seed, mode, (~same).sum(), same.size)
+        assert int(gc.rays_closest) == int(rc.rays_closest)
     ds.close()
 
 
