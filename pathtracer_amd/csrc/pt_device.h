@@ -103,6 +103,14 @@ struct SceneDev {
   const ptl::TexRec *textures;
   const uint8_t *texels;
   uint32_t n_tex;                 // 0 when no material has a diffuse map
+  // Where the interval of a box test starts for boxes the reference never tests, set per launch.  A leaf box
+  // reaches at least 2e-5 beyond its triangles on every axis on which it is not exactly flat, so a ray with
+  // |d| <= 2 is still inside at t = 1e-5 wherever a hit lies in it, and the reference's EPSILON
+  // (object.cpp:180) serves (a flat axis is a flat gate's plane, which the reference tests with that EPSILON
+  // itself): launches whose rays are all that short (bounce and visibility rays are normalised) use 1e-5.  A
+  // longer direction vector can leave the box before t = 1e-5 with a hit at t >= 1e-6 inside: launches that
+  // may hold such rays (callers' own rays, camera rays of a wide viewport) use PT_OWN_BOX_TMIN.
+  float tmin_own;
   uint32_t n_nodes, n_tris, n_lights, n_mats;
   // the fast mode's own tree (pt_fasttree.cpp): four-child nodes, triangle records in its leaf order,
   // the global triangle id and texture coordinates per such record, the gate boxes
@@ -134,6 +142,11 @@ struct HitRec {
 // reference never tests, are widened by the flattener for the same reason.)
 #define PT_SLACK_REL 2.44140625e-4f
 #define PT_SLACK_ABS 2.0e-5f
+// Where the interval of a box test starts for boxes the reference never tests (the fast tree's, and the
+// widened leaf and group boxes of the reference-shaped tree) when the ray's direction vector is long: below
+// the smallest t a triangle hit can have (1e-6, object.cpp:425), so that no box is left before a hit inside
+// it can count.  See SceneDev::tmin_own.
+#define PT_OWN_BOX_TMIN 5.0e-7f
 
 // Which tree a traversal mode walks, and whether it prunes.
 __host__ __device__ constexpr bool mode_prunes(int mode) { return mode != PT_TRACE_EXACT; }
@@ -470,11 +483,14 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
       const pt_f2 bx01 = (pair2(fx.x, fx.y) - ofx) * ix, bx23 = (pair2(fx.z, fx.w) - ofx) * ix;
       const pt_f2 by01 = (pair2(fy.x, fy.y) - ofy) * iy, by23 = (pair2(fy.z, fy.w) - ofy) * iy;
       const pt_f2 bz01 = (pair2(fz.x, fz.y) - ofz) * iz, bz23 = (pair2(fz.z, fz.w) - ofz) * iz;
-      // NaN (a plane through the origin of a ray parallel to it) never restricts
-      const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax01.x), ay01.x), az01.x), tf0 = fminf(fminf(fminf(far, bx01.x), by01.x), bz01.x);
-      const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax01.y), ay01.y), az01.y), tf1 = fminf(fminf(fminf(far, bx01.y), by01.y), bz01.y);
-      const float tn2 = fmaxf(fmaxf(fmaxf(1e-5f, ax23.x), ay23.x), az23.x), tf2 = fminf(fminf(fminf(far, bx23.x), by23.x), bz23.x);
-      const float tn3 = fmaxf(fmaxf(fmaxf(1e-5f, ax23.y), ay23.y), az23.y), tf3 = fminf(fminf(fminf(far, bx23.y), by23.y), bz23.y);
+      // NaN (a plane through the origin of a ray parallel to it) never restricts.  The interval starts at
+      // S.tmin_own: these boxes are this tree's own, a triangle hit counts from t = 1e-6
+      // (object.cpp:425), and a leaf box a margin thick can be left before the reference's EPSILON = 1e-5
+      // by a ray with a long direction vector.
+      const float tn0 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.x), ay01.x), az01.x), tf0 = fminf(fminf(fminf(far, bx01.x), by01.x), bz01.x);
+      const float tn1 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.y), ay01.y), az01.y), tf1 = fminf(fminf(fminf(far, bx01.y), by01.y), bz01.y);
+      const float tn2 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.x), ay23.x), az23.x), tf2 = fminf(fminf(fminf(far, bx23.x), by23.x), bz23.x);
+      const float tn3 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.y), ay23.y), az23.y), tf3 = fminf(fminf(fminf(far, bx23.y), by23.y), bz23.y);
       const bool h0 = tf0 >= tn0, h1 = tf1 >= tn1, h2 = tf2 >= tn2, h3 = tf3 >= tn3;
       if (h0 || h1 || h2 || h3) {
         // nearest child next; the others wait on the stack
@@ -519,16 +535,24 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
       const pt_f2 by = (pair2(st.sy ? q0.y : q1.x, st.sy ? q1.w : q2.z) - splat2(st.of.y)) * splat2(st.iy);
       const pt_f2 az = (pair2(st.sz ? q1.y : q0.z, st.sz ? q2.w : q2.x) - splat2(st.on.z)) * splat2(st.iz);
       const pt_f2 bz = (pair2(st.sz ? q0.z : q1.y, st.sz ? q2.x : q2.w) - splat2(st.of.z)) * splat2(st.iz);
-      // tmin starts at EPSILON, tmax at the cull distance; NaN never updates (object.cpp:180,188-191)
-      const float tn0 = fmaxf(fmaxf(fmaxf(1e-5f, ax.x), ay.x), az.x), tf0 = fminf(fminf(fminf(far, bx.x), by.x), bz.x);
-      const float tn1 = fmaxf(fmaxf(fmaxf(1e-5f, ax.y), ay.y), az.y), tf1 = fminf(fminf(fminf(far, bx.y), by.y), bz.y);
+      // tmin starts at EPSILON, tmax at infinity; NaN never updates (object.cpp:180,188-191).  That is the
+      // test of an internal node of the reference tree, and it stays exactly that in the pruning walk too:
+      // its box has no margin, so its entry distance says nothing reliable about the t of a hit below it (a
+      // hit point a rounding error outside the box, a ray nearly parallel to that face) and it is not skipped
+      // by distance.  Leaf and group boxes are the flattener's own, widened: they start at S.tmin_own
+      // and end at the cull distance.
+      const bool int0 = !PRUNE || q3.z == KIND_INTERNAL, int1 = !PRUNE || q3.w == KIND_INTERNAL;
+      const float tn0 = fmaxf(fmaxf(fmaxf(int0 ? 1e-5f : S.tmin_own, ax.x), ay.x), az.x);
+      const float tn1 = fmaxf(fmaxf(fmaxf(int1 ? 1e-5f : S.tmin_own, ax.y), ay.y), az.y);
+      const float tf0 = fminf(fminf(fminf(int0 ? __builtin_inff() : far, bx.x), by.x), bz.x);
+      const float tf1 = fminf(fminf(fminf(int1 ? __builtin_inff() : far, bx.y), by.y), bz.y);
       bool p0, p1;
       if (!PRUNE) {
         // only an internal node of the reference tree is box-tested there (object.cpp:277)
         p0 = (q3.z == KIND_INTERNAL) ? (tf0 >= tn0) : true;
         p1 = (q3.w == KIND_INTERNAL) ? (tf1 >= tn1) : true;
       } else {
-        // leaf and group boxes were widened by the flattener, and tf started at the cull
+        // leaf and group boxes were widened by the flattener, and their tf started at the cull
         // distance, so one comparison covers the box test and the pruning
         p0 = tf0 >= tn0;
         p1 = tf1 >= tn1;

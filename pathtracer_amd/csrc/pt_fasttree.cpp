@@ -280,6 +280,14 @@ struct FastBuilder {
       }
       if (all)
         for (int k = 0; k < 3; ++k) {
+          // Clipped planes have no margin, and a plane without margin must not decide a skip by distance: a
+          // computed hit point can lie a rounding error outside it, and for a ray nearly parallel to the plane
+          // that error is a large difference between the box's entry distance and the hit's t.  Two cases are
+          // safe.  A gate that is flat on this axis: its triangles lie in that very plane, so entry distance
+          // and t are the same quantity (this is the clipping that pays: a ray leaving a wall does not enter
+          // the wall's box).  A leaf that is never skipped by distance (ill-conditioned, REF_NOCULL all the way
+          // down): only the pass/miss decision uses its planes, and a ray that passes the gate passes them.
+          if (!ill[i] && !(g.lo[k] == g.hi[k])) continue;
           if (g.lo[k] > w.lo[k]) w.lo[k] = g.lo[k];   // NaN planes leave the widened box alone
           if (g.hi[k] < w.hi[k]) w.hi[k] = g.hi[k];
         }

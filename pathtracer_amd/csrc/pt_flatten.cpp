@@ -539,6 +539,7 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
     return PT_ERR_INVALID;
   }
   std::vector<uint8_t> seen(n_tris, 0), node_seen(f.nodes4.size(), 0);
+  const float leaf_margin = f.margin_rel * f.max_abs_coord + 2.0e-5f;
   struct Item { uint32_t node; float lo[3], hi[3]; bool nocull; };
   std::vector<Item> todo;
   Item root;
@@ -569,6 +570,15 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
           for (int v = 0; v < 3; ++v)
             for (int k = 0; k < 3; ++k)
               if (p[3 * v + k] < lo[k] || p[3 * v + k] > hi[k]) { err = "fast tree: triangle outside its leaf box"; return PT_ERR_INVALID; }  // a gate box holds its triangles too
+          // a leaf that distance can skip keeps a margin around its triangles on every axis on which its box is
+          // not exactly flat (a flat one is a flat gate's plane, in which the triangles lie)
+          if (!path_nocull && !triangle_is_ill_conditioned(p))
+            for (int k = 0; k < 3; ++k) {
+              if (lo[k] == hi[k]) continue;
+              float vmin = p[k], vmax = p[k];
+              for (int v = 1; v < 3; ++v) { vmin = std::fmin(vmin, p[3 * v + k]); vmax = std::fmax(vmax, p[3 * v + k]); }
+              if (!(lo[k] <= vmin - 0.5f * leaf_margin) || !(hi[k] >= vmax + 0.5f * leaf_margin)) { err = "fast tree: a leaf box plane without margin"; return PT_ERR_INVALID; }
+            }
           if (f.tris4[t].gate != NO_GATE && f.tris4[t].gate >= f.gates.size()) { err = "fast tree: gate index out of range"; return PT_ERR_INVALID; }
         }
       } else {

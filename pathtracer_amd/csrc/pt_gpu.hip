@@ -117,6 +117,7 @@ struct PtScene {
   unsigned long long *h_stats = nullptr;   // pinned
   bool count_stats = false;
   bool profile = false;
+  bool short_rays = false;                 // the rays of the next launches all have |d| <= 2 (SceneDev::tmin_own)
   uint32_t tail_paths = 0;                 // PT_TAIL: a batch with at most this many live paths is finished by k_tail (0: never)
   bool tail_given = false;                 // PT_TAIL was set; otherwise tail_limit() chooses
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -288,6 +289,7 @@ static const Plan &plan_of(const PtScene *s, int mode) { return mode_wide(mode) 
 static SceneDev dev_of(const PtScene *s, int mode) {
   SceneDev d = s->dev;
   d.quorum_any = plan_of(s, mode).quorum_any;
+  d.tmin_own = s->short_rays ? 1e-5f : PT_OWN_BOX_TMIN;
   return d;
 }
 
@@ -1038,6 +1040,10 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
   uint32_t *cnt = s->acnt;
   const bool cs = s->count_stats;
   const bool prof = s->profile;
+  // longest camera ray: a corner of the viewport (the rotation keeps lengths), plus what the lens offset adds
+  double dmax = std::sqrt(0.25 * (double)F.vw * F.vw + 0.25 * (double)F.neg_vh * F.neg_vh + (double)F.pin_z * F.pin_z);
+  if (F.aperture > 0.0f) dmax += (double)F.aperture * std::fabs((double)F.pin_z) / (double)F.focus;
+  const bool long_camera_rays = !(dmax * dmax <= 3.9);
   auto elapsed = [&](int a, int b, double &acc) -> int {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[a], s->ev[b]));
@@ -1062,6 +1068,8 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
     for (int depth = 0; n > 0; ++depth) {
       if (depth > 100000) return fail(PT_ERR_DEVICE, "path did not terminate after 100000 vertices");
       HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), st));
+      // bounce and visibility rays are normalised; camera rays are as long as the viewport makes them
+      s->short_rays = depth > 0 || !long_camera_rays;
       if (n <= tail_limit(s, o.trace_mode)) {
         // few paths left: one kernel follows each of them to its end
         if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
@@ -1225,6 +1233,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
   if (rc == PT_OK) rc = leave_stream(s, st);
   s->aw = &s->ws;
   s->acnt = s->d_cnt;
+  s->short_rays = false;  // whatever render_batches left: the ray queries make no assumption about their rays
   if (rc == PT_OK && counters) *counters = c;
   return rc;
 }
