@@ -19,6 +19,8 @@ for seed in range(first, last + 1):
     W, H, spp = 48, 40, 3
     cam = dict(origin=(float(rng.uniform(-1, 1)) * scale, float(rng.uniform(-1, 1)) * scale, -1.5 * scale),
                euler=(float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), 0.0))
+    if rng.random() < 0.5:  # a wide viewport: camera rays with long direction vectors
+        cam["vw"] = int(rng.choice([4, 16, 64])); cam["vh"] = cam["vw"] * 3 // 4
     kw = {}
     if rng.random() < 0.5: kw["max_depth"] = int(rng.integers(1, 6))
     if rng.random() < 0.5: kw["sampling"] = 1
