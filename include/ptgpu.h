@@ -47,6 +47,11 @@ typedef enum PtStatus {
  *                nodes[index_or_first + 1];
  * count  > 0  -> leaf over objects[index_or_first .. index_or_first + count).
  * 32 bytes.
+ * Boxes must be what the reference's builder makes them (BVH::update_box, object.cpp:296-308): the box of an
+ * internal node encloses the boxes of the internal nodes and the triangles below it.  PT_TRACE_FAST relies on
+ * that (it tests the lowest internal box above a triangle in place of all of them); pt_scene_upload and
+ * pt_scene_check verify it, report it in PtSceneInfo.boxes_nested, and a scene whose boxes are not nested is
+ * walked with PT_TRACE_EXACT whatever mode is asked for.
  */
 typedef struct PtNode {
   uint32_t index_or_first;
@@ -112,6 +117,8 @@ typedef struct PtSceneInfo {
   uint32_t n_gates;        /* internal nodes of the reference's trees (their boxes gate the fast mode's hits) */
   uint32_t device;         /* HIP device ordinal the scene lives on */
   uint64_t device_bytes;   /* bytes of HBM held by the scene */
+  uint32_t boxes_nested;   /* 1: every internal box encloses what is below it (see PtNode); 0: PT_TRACE_FAST runs as PT_TRACE_EXACT */
+  uint32_t reserved;
 } PtSceneInfo;
 
 /* Camera state read by Camera::render (camera.cpp:49-58,161-169).  `euler` is
@@ -133,10 +140,11 @@ enum { PT_SAMPLE_UNIFORM = 0, PT_SAMPLE_COSINE = 1 };
  * that triangle.  PT_TRACE_FAST_BINARY is the pruned walk over the reference-shaped trees, kept for
  * comparison (on a scene with an ill-conditioned triangle it is the exact walk).
  * The pruning modes skip boxes with a margin of 2^-16 of the scene's largest coordinate; the rounding error of
- * a box test grows with the distance of the ray's origin, so they return the reference's hits for origins
- * within 16 times that coordinate of the world origin (measured: no mismatch in 600 000 rays at 10 times, the
- * first at 100 times).  pt_render and pt_render_dev switch to PT_TRACE_EXACT by themselves when the camera
- * stands farther away; callers of the ray queries with such origins pass PT_TRACE_EXACT. */
+ * a box test grows with the distance of the ray's origin, so they are used for origins within 16 times that
+ * coordinate of the world origin (measured: no mismatch in 600 000 rays at 10 times, the first at 100 times)
+ * and every entry point sees to that by itself: pt_render and pt_render_dev run PT_TRACE_EXACT when the
+ * camera stands farther away, and the ray queries (pt_trace_closest[_dev], pt_trace_any, pt_trace_hits) walk
+ * every ray whose origin lies beyond that range (or is not finite) exactly, ray by ray, in a second launch. */
 enum { PT_TRACE_EXACT = 0, PT_TRACE_FAST = 1, PT_TRACE_FAST_BINARY = 2 };
 
 /* Integrator constants.  pt_options_default() fills in the reference literals
@@ -190,13 +198,16 @@ void pt_camera_default(PtCamera *cam);
  * flattens both BVH levels into one device tree, orders triangle slots so that
  * the slot index is the tie-break rank of BVH::intersect (object.cpp:265-285),
  * and builds the light table of Scene::lights() (scene.cpp:22-30) with the
- * areas of Triangle::area / Polygon::area (object.cpp:395-404,493-495). */
+ * areas of Triangle::area / Polygon::area (object.cpp:395-404,493-495).
+ * Rejects a malformed description with PT_ERR_INVALID; one whose boxes are not nested (see PtNode) is
+ * accepted and walked exactly. */
 int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out);
 void pt_scene_free(PtScene *scene);
 int pt_scene_info(const PtScene *scene, PtSceneInfo *info);
 /* Host only (needs no device): runs the conversion pt_scene_upload would run, verifies the description
- * and the invariants of the trees built from it (every triangle in exactly one leaf, boxes nested,
- * references in range) and fills in the counts of `info` (device and device_bytes stay 0; may be null). */
+ * and the invariants of the trees built from it (every triangle in exactly one leaf, the fast tree's own
+ * boxes nested and wide enough, references in range), checks whether the description's boxes are nested
+ * (info->boxes_nested, see PtNode) and fills in the counts of `info` (device and device_bytes stay 0; may be null). */
 int pt_scene_check(const PtSceneDesc *desc, PtSceneInfo *info);
 
 /* Work counters (PtCounters.node_boxes / tri_tests): off by default.  When on,
@@ -223,7 +234,9 @@ int pt_trace_closest(PtScene *scene, size_t n,
                      float *t, int32_t *tri, float *u, float *v, int mode);
 
 /* Same with device pointers on the scene's device; enqueues on `stream`
- * (a hipStream_t, may be null) and does not wait. */
+ * (a hipStream_t, may be null) and does not wait.  In a pruning mode this is two launches: the pruning walk
+ * for the rays whose origin is within its range, the exact walk for the others (see PT_TRACE_FAST); the
+ * host-pointer form looks at the origins first and leaves the second launch out when none needs it. */
 int pt_trace_closest_dev(PtScene *scene, size_t n,
                          const float *ox, const float *oy, const float *oz,
                          const float *dx, const float *dy, const float *dz,
@@ -272,6 +285,17 @@ int pt_render_dev(PtScene *scene, const PtCamera *cam, int W, int H,
                   const PtOptions *opt, float *accum_rgb_sum_dev,
                   PtCounters *counters, void *stream);
 
+/* Seam B with the reference's own accumulator (camera.cpp:182-198): pixels_dev (W*H*3 floats on the scene's
+ * device) holds Camera::pixels after `pass_begin` passes (all zeros for pass_begin == 0, camera.cpp:177-179)
+ * and is updated by passes pass_begin .. pass_begin + pass_count - 1 with the reference's running mean,
+ * pixels = (i * pixels + radiance * 255) / (i + 1), in float as vector_'s operators evaluate it
+ * (math.cpp:168-183).  Pass i uses global sample index i; opt->spp_stride must be 1.  A progressive caller
+ * (RenderThread::run, main.cpp:40-52) calls this once per callback interval and reads the pixels, or their
+ * display conversion (pt_display_dev), back.  Otherwise like pt_render_dev. */
+int pt_render_mean_dev(PtScene *scene, const PtCamera *cam, int W, int H,
+                       uint32_t pass_begin, uint32_t pass_count, uint64_t seed,
+                       const PtOptions *opt, float *pixels_dev, PtCounters *counters, void *stream);
+
 /* Seam B over several devices of one node (camera.cpp:171-200; the reference's only parallelism is
  * parallel_for over OS threads, camera.cpp:14-39).  scenes[g] is a copy of the same scene on its own
  * device (pt_scene_upload once per device).  The samples spp_begin + j*spp_stride, j in [0, spp_count),
@@ -289,28 +313,60 @@ int pt_render_multi(PtScene *const *scenes, int n_scenes, const PtCamera *cam, i
 #define PT_STATIC_SCRATCH_BYTES (64u << 20)
 
 /*
- * pt_render_dev for callers that cannot allocate: code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * pt_render_dev for callers that cannot allocate: tight serving loops, harnesses that forbid
+ * hipMalloc, code that must not disturb the allocator.  It has no counterpart in the reference.
  * Same arguments, same result bit for bit, but no hipMalloc / hipFree or other allocating
  * call: the counters, path queues, hit records and visibility rays live in a static device
  * array of PT_STATIC_SCRATCH_BYTES (64 MiB) that every GPU the library runs on holds until
- * the process ends.  That caps the frame: one sample of every pixel must fit, at about
- * 150 bytes per pixel (+ 12 + 25 per light for scenes too large for on-chip memory), i.e.
- * up to about 440 000 pixels (e.g. 800x450; the reference's own 256x256 with 6 samples in
- * flight); a larger frame is rejected with PT_ERR_UNSUPPORTED and a message naming the sizes.
+ * the process ends.  That caps the frame: one sample of every pixel must fit, at 178 bytes
+ * per pixel (+ 12 + 25 per light for scenes too large for on-chip memory), i.e. up to about
+ * 375 000 pixels (e.g. 800x450; the reference's own 256x256 with 5 samples in flight);
+ * pt_static_max_pixels() gives the limit for a scene, and a larger frame is rejected with
+ * PT_ERR_UNSUPPORTED and a message naming the sizes.
+ * Like pt_render_dev the call is not "enqueue and return": it waits for the stream once per
+ * depth level (it reads the number of surviving paths to size the next launches), so it
+ * cannot run inside a HIP graph capture.
  * All scenes on one GPU share that GPU's array and it keeps the last call's contents (the
- * call clears what must start at zero): calls that overlap in time on one GPU race, whether
- * on one scene or several; run them one after the other.
+ * call clears what must start at zero).  Calls on one GPU are ordered on the device by an
+ * event per GPU (each waits for the previous one's kernels, whatever scene and stream that
+ * one named); calls issued from several host threads at the same time still race on the host
+ * side: issue them one after the other.
  */
 int pt_render_dev_static(PtScene *scene, const PtCamera *cam, int W, int H,
                          uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
                          const PtOptions *opt, float *accum_rgb_sum_dev,
                          PtCounters *counters, void *stream);
 uint64_t pt_static_scratch_bytes(void);
+/* Largest W*H pt_render_dev_static accepts for this scene in the given trace mode. */
+uint64_t pt_static_max_pixels(const PtScene *scene, int trace_mode);
+
+/* The sample dealing of pt_render_multi and of one-process-per-GPU callers, as a function: shard `shard` of
+ * `n_shards` renders `*count` samples with global indices *begin + k * *stride.  The union over the shards is
+ * spp_begin + j*spp_stride, j in [0, spp_count), each exactly once.  (The reference's only split of the work is
+ * parallel_for over rows, camera.cpp:14-39.) */
+int pt_shard_samples(uint32_t spp_begin, uint32_t spp_count, uint32_t spp_stride, uint32_t shard, uint32_t n_shards,
+                     uint32_t *begin, uint32_t *count, uint32_t *stride);
 
 /* Resolve sums to the reference's pixel values: out = sum / spp * 255
  * (camera.cpp:188-190), host memory, n floats. */
 int pt_resolve(const float *accum_rgb_sum, size_t n, uint32_t spp, float *pixels);
+/* The same on the device (both arrays on `device`, n floats), enqueued on `stream`. */
+int pt_resolve_dev(const float *accum_rgb_sum_dev, size_t n, uint32_t spp, float *pixels_dev, int device, void *stream);
+/* The display conversion of the reference's per-pass callback (main.cpp:43-47) from the sums, on the device:
+ * rgb8[3*p+c] = clamp((int)(sum / spp * 255), 0, 255) with the x86-64 conversion the reference's build
+ * performs (toward zero; out of int range or NaN -> INT_MIN -> 0).  n_pixels pixels, enqueued on `stream`. */
+int pt_resolve_display_dev(const float *accum_rgb_sum_dev, size_t n_pixels, uint32_t spp, uint8_t *rgb8_dev,
+                           int device, void *stream);
+/* The same conversion from Camera::pixels themselves (as pt_render_mean_dev keeps them). */
+int pt_display_dev(const float *pixels_dev, size_t n_pixels, uint8_t *rgb8_dev, int device, void *stream);
+
+/* Device memory for hosts without a HIP toolchain of their own (the C++ Camera keeps its accumulator on the
+ * device across the passes of a progressive render, camera.cpp:182-198): zeroed allocation, release, clear
+ * (enqueued), and a copy to host memory that waits for `stream`.  No counterpart in the reference. */
+int pt_device_alloc(int device, size_t bytes, void **out);
+int pt_device_free(int device, void *ptr);
+int pt_device_clear(int device, void *ptr, size_t bytes, void *stream);
+int pt_device_read(int device, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 
 /* The counter-based generator, exposed so that tests can pin it:
  * Philox-4x32-10 with counter (c0,c1,c2,c3) and key (k0,k1). */

@@ -42,7 +42,7 @@ class PtSceneInfo(C.Structure):
     _fields_ = [("n_meshes", C.c_uint32), ("n_tris", C.c_uint32), ("n_lights", C.c_uint32),
                 ("n_wide_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("n_fast_nodes", C.c_uint32),
                 ("fast_max_depth", C.c_uint32), ("n_gates", C.c_uint32), ("device", C.c_uint32),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("boxes_nested", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PtCamera(C.Structure):
@@ -81,6 +81,8 @@ EXPORTS = [
     "pt_scene_read_profile", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_trace_any", "pt_trace_hits", "pt_camera_rays", "pt_render", "pt_render_dev", "pt_resolve",
     "pt_philox4x32", "pt_roulette_pass", "pt_render_dev_static", "pt_static_scratch_bytes", "pt_render_multi",
+    "pt_static_max_pixels", "pt_shard_samples", "pt_resolve_dev", "pt_resolve_display_dev",
+    "pt_device_alloc", "pt_device_free", "pt_device_clear", "pt_device_read", "pt_render_mean_dev", "pt_display_dev",
 ]
 
 
@@ -128,10 +130,21 @@ def lib():
                                 C.c_uint64, C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtCounters)]
         L.pt_render_dev.argtypes = L.pt_render.argtypes + [C.c_void_p]
         L.pt_render_dev_static.argtypes = L.pt_render_dev.argtypes
+        L.pt_render_mean_dev.argtypes = L.pt_render_dev.argtypes
+        L.pt_display_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
         L.pt_static_scratch_bytes.restype = C.c_uint64
         L.pt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(PtCamera), C.c_int, C.c_int, C.c_uint32,
                                       C.c_uint32, C.c_uint64, C.POINTER(PtOptions), C.c_void_p, C.POINTER(PtCounters)]
         L.pt_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+        L.pt_static_max_pixels.restype = C.c_uint64
+        L.pt_static_max_pixels.argtypes = [C.c_void_p, C.c_int]
+        L.pt_shard_samples.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32)] * 3
+        L.pt_resolve_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+        L.pt_resolve_display_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+        L.pt_device_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.pt_device_free.argtypes = [C.c_int, C.c_void_p]
+        L.pt_device_clear.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.pt_device_read.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.pt_philox4x32.argtypes = [C.c_void_p] * 3
         L.pt_philox4x32.restype = None
         L.pt_roulette_pass.argtypes = [C.c_double, C.c_float]
@@ -194,6 +207,26 @@ def resolve(accum, spp):
     out = np.empty_like(a)
     _check(lib().pt_resolve(_p(a), a.size, spp, _p(out)))
     return out
+
+
+def shard_samples(spp_begin, spp_count, spp_stride, shard, n_shards):
+    """pt_shard_samples: (begin, count, stride) of the samples shard `shard` of `n_shards` renders."""
+    b, c, st = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _check(lib().pt_shard_samples(spp_begin, spp_count, spp_stride, shard, n_shards, C.byref(b), C.byref(c), C.byref(st)))
+    return b.value, c.value, st.value
+
+
+def resolve_dev(accum_ptr, n, spp, out_ptr, device=0, stream=None):
+    _check(lib().pt_resolve_dev(C.c_void_p(accum_ptr), n, spp, C.c_void_p(out_ptr), device, C.c_void_p(stream or 0)))
+
+
+def resolve_display_dev(accum_ptr, n_pixels, spp, rgb_ptr, device=0, stream=None):
+    _check(lib().pt_resolve_display_dev(C.c_void_p(accum_ptr), n_pixels, spp, C.c_void_p(rgb_ptr), device,
+                                        C.c_void_p(stream or 0)))
+
+
+def display_dev(pixels_ptr, n_pixels, rgb_ptr, device=0, stream=None):
+    _check(lib().pt_display_dev(C.c_void_p(pixels_ptr), n_pixels, C.c_void_p(rgb_ptr), device, C.c_void_p(stream or 0)))
 
 
 def _make_desc(arrays):
@@ -313,6 +346,9 @@ class DeviceScene:
     def handle(self):
         return self._h
 
+    def static_max_pixels(self, mode=PT_TRACE_FAST):
+        return int(lib().pt_static_max_pixels(self._h, mode))
+
     def count_stats(self, enable):
         _check(lib().pt_scene_count_stats(self._h, int(enable)))
 
@@ -382,6 +418,14 @@ class DeviceScene:
         o = opt if opt is not None else make_options()
         _check(lib().pt_render_dev(self._h, C.byref(cam), W, H, spp_begin, spp_count, seed, C.byref(o),
                                    C.c_void_p(accum_ptr), C.byref(cnt), C.c_void_p(stream or 0)))
+        return cnt
+
+    def render_mean_dev(self, cam, W, H, pass_count, pixels_ptr, pass_begin=0, seed=0, opt=None, stream=None):
+        """pt_render_mean_dev: updates Camera::pixels (running mean of radiance*255) at `pixels_ptr` on the device."""
+        cnt = PtCounters()
+        o = opt if opt is not None else make_options()
+        _check(lib().pt_render_mean_dev(self._h, C.byref(cam), W, H, pass_begin, pass_count, seed, C.byref(o),
+                                        C.c_void_p(pixels_ptr), C.byref(cnt), C.c_void_p(stream or 0)))
         return cnt
 
     def render_dev_static(self, cam, W, H, spp_count, accum_ptr, spp_begin=0, seed=0, opt=None, stream=None):

@@ -27,6 +27,11 @@ class Camera {
   std::vector<int> devices;        // more than one entry: the samples are dealt over these devices (pt_render_multi)
   uint32_t spp_begin = 0;          // global index of this render's first sample (a shard of a larger frame)
   PtCounters counters{};           // work done by the last render()
+  // Progressive display (main.cpp:40-52: the GUI's callback turns `pixels` into clamped 8-bit colours after every
+  // pass).  With display_only the conversion runs on the device and every callback interval copies back only
+  // these bytes, display[(py*OUTW+px)*3 + c]; `pixels` is then filled once, after the last pass.
+  bool display_only = false;
+  std::vector<unsigned char> display;
 
   explicit Camera(const vec &origin, const vec &direction = vec(0, 0, 0));
 
@@ -36,8 +41,9 @@ class Camera {
   // Camera::render (camera.cpp:171-200).  Clears `pixels`, renders `samples` samples per
   // pixel on the GPU and leaves radiance * 255 averaged over the samples in `pixels`.
   // With a callback the image is refreshed and cb() called after every `passes_per_callback`
-  // samples (1 = after every pass, as the reference does).  Throws std::runtime_error on a
-  // device failure.
+  // samples (1 = after every pass, as the reference does).  On one device the radiance sums live in
+  // device memory for the whole call; nothing is allocated or uploaded per pass.  Throws
+  // std::runtime_error on a device failure.
   void render(const Scene &scene, int samples = 32, std::function<void()> cb = nullptr,
               int passes_per_callback = 1);
 

@@ -188,6 +188,35 @@ int pth_camera_render(void *h, const PtCamera *c, const PtOptions *opt, int W, i
   }
 }
 
+// The same render with the display conversion on the device (Camera::display_only): rgb[H*W*3] receives the
+// clamped bytes after every callback interval, pixels[H*W*3] (may be null) the float image at the end.
+int pth_camera_render_display(void *h, const PtCamera *c, const PtOptions *opt, int W, int H, int samples, uint64_t seed,
+                              int device, uint8_t *rgb, float *pixels, void (*cb)(void), int every) {
+  try {
+    Camera cam(vec(c->origin[0], c->origin[1], c->origin[2]), vec(c->euler[0], c->euler[1], c->euler[2]));
+    cam.OUTW = W; cam.OUTH = H; cam.vw = c->vw; cam.vh = c->vh; cam.fov = c->fov_deg;
+    cam.aperture = c->aperture; cam.focus = c->focus;
+    cam.seed = seed; cam.device = device;
+    cam.display_only = true;
+    if (opt) {
+      cam.options = *opt;
+      cam.bgcolor = vec(opt->bgcolor[0], opt->bgcolor[1], opt->bgcolor[2]);
+    }
+    std::function<void()> f;
+    if (cb) f = [&]() {
+      memcpy(rgb, cam.display.data(), (size_t)W * H * 3);
+      cb();
+    };
+    cam.render(static_cast<Handle *>(h)->scene, samples, f, every);
+    memcpy(rgb, cam.display.data(), (size_t)W * H * 3);
+    if (pixels) memcpy(pixels, cam.pixels.data(), (size_t)W * H * 3 * sizeof(float));
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 int pth_save_ppm(const char *path, const float *pixels, int W, int H) {
   Camera cam(vec(0, 0, 0));
   cam.OUTW = W; cam.OUTH = H;

@@ -20,21 +20,19 @@ static void usage(const char *argv0) {
                "          [--origin x,y,z] [--euler a,b,c] [--fov deg] [--aperture r --focus d]\n"
                "          [--max-depth k] [--cosine] [--exact] [--seed s] [--device i] [--devices n] [--progress]\n"
                "          [--save-cache scene.ptscene]   (a .ptscene file is also accepted as the scene)\n"
-               "          [--heatmap]   (instead of rendering: HitData::hits of every primary ray as a grey image)\n",
+               "          [--heatmap]   (instead of rendering: HitData::hits of every primary ray as a grey image)\n"
+               "          [--display]   (write what the reference's window shows: colours clamped to 0..255, binary PPM)\n",
                argv0);
 }
 
 static bool parse3(const char *s, vec &v) { return std::sscanf(s, "%f,%f,%f", &v.x, &v.y, &v.z) == 3; }
 
-// The display conversion of the GUI callback (main.cpp:43-47): clamp((int)value, 0, 255).
+// The display image of the GUI callback (main.cpp:43-47: clamp((int)value, 0, 255)), converted on the device
+// by Camera::render (display_only) and written as a binary PPM.
 static void write_display_ppm(const Camera &cam, const std::string &path) {
   std::ofstream ofs(path, std::ios::binary);
   ofs << "P6\n" << cam.OUTW << " " << cam.OUTH << "\n255\n";
-  auto norm = [](double i) { return (unsigned char)std::clamp((int)i, 0, 255); };
-  for (const vec &p : cam.pixels) {
-    const unsigned char rgb[3] = {norm(p.x), norm(p.y), norm(p.z)};
-    ofs.write(reinterpret_cast<const char *>(rgb), 3);
-  }
+  ofs.write(reinterpret_cast<const char *>(cam.display.data()), (std::streamsize)cam.display.size());
 }
 
 int main(int argc, char **argv) {
@@ -132,6 +130,7 @@ int main(int argc, char **argv) {
     }
     const auto t0 = std::chrono::steady_clock::now();
     int pass = 0;
+    cam.display_only = display;
     if (progress)
       cam.render(scene, spp, [&]() { std::printf("pass %d/%d\n", ++pass, spp); });
     else

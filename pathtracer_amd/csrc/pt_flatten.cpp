@@ -209,9 +209,24 @@ struct Flattener {
     return (uint32_t)out.gates.size() - 1;
   }
 
+  // The fast traversal tests one box per triangle, the lowest internal box above it (its gate), in place of
+  // every internal box above it.  The two agree when each internal box lies inside the one above it and the
+  // triangles inside the lowest (the reference's builder makes boxes the exact unions of what is below them,
+  // object.cpp:296-308).  A description that breaks this is counted here and then walked exactly.
+  void check_inside(const float lo[3], const float hi[3], uint32_t gate) {
+    if (gate == NO_GATE) return;
+    const GateBox &g = out.gates[gate];
+    for (int k = 0; k < 3; ++k)
+      if (lo[k] < g.lo[k] || hi[k] > g.hi[k]) {  // NaN planes compare false: they restrict no ray either
+        ++out.n_unnested;
+        return;
+      }
+  }
+
   void put_triangle(uint32_t mesh, uint32_t local, uint32_t levels, uint32_t gate) {
     const uint32_t gid = d.tri_offset[mesh] + local;
     const float *p = d.tri_verts + (size_t)gid * 9;
+    for (int v = 0; v < 3; ++v) check_inside(p + 3 * v, p + 3 * v, gate);
     TriRec r;
     for (int k = 0; k < 3; ++k) {
       r.v0[k] = p[k];
@@ -254,6 +269,7 @@ struct Flattener {
       if (next_slot > MAX_TRI_SLOTS) return fail("more than 2^28 triangles");
       return split_leaf(first_slot, next_slot);
     }
+    check_inside(n.bmin, n.bmax, gate);
     const uint32_t own = add_gate(n);
     Entry l = mesh_node(mesh, n.index_or_first, level + 1, inner + 1, own);
     Entry r = mesh_node(mesh, n.index_or_first + 1, level + 1, inner + 1, own);
@@ -286,6 +302,7 @@ struct Flattener {
       }
       return group(es, 0, es.size());
     }
+    check_inside(n.bmin, n.bmax, gate);
     const uint32_t own = add_gate(n);
     Entry l = tlas_node(n.index_or_first, level + 1, inner + 1, own);
     Entry r = tlas_node(n.index_or_first + 1, level + 1, inner + 1, own);

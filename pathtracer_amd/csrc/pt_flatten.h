@@ -33,6 +33,7 @@ struct FlatScene {
   uint32_t max_depth = 0;            // stack entries the deepest descent needs
   uint32_t n_meshes = 0;
   float max_abs_coord = 0;           // largest |coordinate| of any vertex
+  uint32_t n_unnested = 0;           // internal boxes and triangle vertices found outside the internal box above them
 };
 
 // Builds nodes4 / tris4 / gate4 / tri_uv4 from tris, tri_gate and the description's vertices.

@@ -107,6 +107,7 @@ struct PtScene {
   float *d_tri_uv4 = nullptr;
   uint32_t max_depth = 0, max_depth4 = 0, n_meshes = 0;
   float max_abs_coord = 0;                 // largest finite vertex coordinate
+  uint32_t n_unnested = 0;                 // boxes / triangles of the description that reach outside the internal box above them
   uint64_t bytes = 0;
   Plan plan;                               // launches over the reference-shaped tree (exact mode, fast-binary mode)
   Plan plan4;                              // launches over the fast tree
@@ -137,6 +138,9 @@ struct PtScene {
 // (every GPU holds its own copy of the array at its own address).
 static const int kMaxDevices = 64;
 static unsigned char *g_scratch_ptr[kMaxDevices];
+// Recorded after every call that worked in a device's static buffer and waited for by the next one, so that such
+// calls are ordered on the GPU whatever scenes and streams they name (the buffer is one per GPU, not per scene).
+static hipEvent_t g_scratch_last[kMaxDevices];
 static std::mutex g_scratch_mutex;
 
 static int setup_static_scratch(int device) {
@@ -145,6 +149,7 @@ static int setup_static_scratch(int device) {
   if (g_scratch_ptr[device]) return PT_OK;
   void *ptr = nullptr;
   HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  HIP_TRY(hipEventCreateWithFlags(&g_scratch_last[device], hipEventDisableTiming));
   g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
   return PT_OK;
 }
@@ -515,7 +520,7 @@ static int launch_tail(PtScene *s, const PathFrame &F, int depth, uint32_t n, co
 template <int MODE, bool COUNT>
 static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz,
                             const float *dx, const float *dy, const float *dz, float *t, int32_t *tri, float *u,
-                            float *v, hipStream_t st) {
+                            float *v, hipStream_t st, RaySide side) {
   HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
   const Plan &P = plan_of(s, MODE);
   const SceneDev D = dev_of(s, MODE);
@@ -525,7 +530,7 @@ static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *
     int rc = allow_lds(k, P.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, run_length(P, n), n, ox, oy, oz,
-                       dx, dy, dz, t, tri, u, v, s->acnt + 2, s->d_stats);
+                       dx, dy, dz, t, tri, u, v, s->acnt + 2, s->d_stats, side);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -533,7 +538,7 @@ static int launch_trace_api(PtScene *s, size_t n, const float *ox, const float *
 
 template <int MODE>
 static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
-                          const float *dy, const float *dz, uint8_t *hit, hipStream_t st) {
+                          const float *dy, const float *dz, uint8_t *hit, hipStream_t st, RaySide side) {
   HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
   const Plan &P = plan_of(s, MODE);
   const SceneDev D = dev_of(s, MODE);
@@ -543,7 +548,7 @@ static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy
     int rc = allow_lds(k, P.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, run_length(P, n), n, ox, oy, oz,
-                       dx, dy, dz, hit, s->acnt + 2);
+                       dx, dy, dz, hit, s->acnt + 2, side);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -551,7 +556,7 @@ static int launch_any_api(PtScene *s, size_t n, const float *ox, const float *oy
 
 template <int MODE>
 static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
-                           const float *dy, const float *dz, int32_t *hits, hipStream_t st) {
+                           const float *dy, const float *dz, int32_t *hits, hipStream_t st, RaySide side) {
   HIP_TRY(hipMemsetAsync(s->acnt, 0, 8 * sizeof(uint32_t), st));
   const Plan &P = plan_of(s, MODE);
   const SceneDev D = dev_of(s, MODE);
@@ -561,7 +566,7 @@ static int launch_hits_api(PtScene *s, size_t n, const float *ox, const float *o
     int rc = allow_lds(k, P.lds_bytes);
     if (rc != PT_OK) return rc;
     hipLaunchKernelGGL(k, grid_for(P, n), dim3(BLOCK), P.lds_bytes, st, D, P.lds, run_length(P, n), n, ox, oy, oz,
-                       dx, dy, dz, s->d_levels, hits, s->acnt + 2);
+                       dx, dy, dz, s->d_levels, hits, s->acnt + 2, side);
     HIP_TRY(hipGetLastError());
     return PT_OK;
   });
@@ -572,8 +577,22 @@ static bool valid_mode(int mode) { return mode == PT_TRACE_EXACT || mode == PT_T
 // The pruning walk of the reference-shaped tree skips leaves by their bounds and by distance; an
 // ill-conditioned triangle can report a hit outside both (triangle_is_ill_conditioned), so a scene that has
 // one is walked exactly instead.  (The fast tree deals with such triangles itself.)
+// The fast tree accepts a hit when the ray passes the lowest internal box above the triangle; that equals the
+// reference's test of every internal box above it only when those boxes are nested (each inside its parent's,
+// the triangles inside the lowest).  The reference's builder makes them so; a description whose boxes are not
+// (refitted, padded or hand-made) is walked exactly.
 static int effective_mode(const PtScene *s, int mode) {
-  return (mode == PT_TRACE_FAST_BINARY && s->dev.n_ill != 0) ? PT_TRACE_EXACT : mode;
+  if (mode == PT_TRACE_FAST_BINARY && s->dev.n_ill != 0) return PT_TRACE_EXACT;
+  if (mode == PT_TRACE_FAST && s->n_unnested != 0) return PT_TRACE_EXACT;
+  return mode;
+}
+// Origins up to this distance from the world origin (per coordinate) are inside the range of the pruning walks.
+static float near_limit(const PtScene *s) { return 16.0f * s->max_abs_coord; }
+// Largest |coordinate| among n origins on the host; NaN counts as beyond every limit.
+static bool host_origins_within(const float *ox, const float *oy, const float *oz, size_t n, float limit) {
+  bool ok = true;
+  for (size_t i = 0; i < n; ++i) ok = ok && (std::fabs(ox[i]) <= limit) && (std::fabs(oy[i]) <= limit) && (std::fabs(oz[i]) <= limit);
+  return ok;
 }
 template <typename F>
 static int with_mode(int mode, F &&f) {
@@ -743,6 +762,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.n_ill = f.n_ill;
   s->dev.margin = f.max_abs_coord * (1.0f / 2048.0f) + 2.0e-5f;
   s->max_abs_coord = f.max_abs_coord;
+  s->n_unnested = f.n_unnested;
   s->dev.quorum = 32;
   s->dev.quorum_any = 32;
   if (const char *e = std::getenv("PT_QUORUM_ANY")) {  // tuning knob
@@ -805,7 +825,9 @@ int pt_scene_check(const PtSceneDesc *desc, PtSceneInfo *info) {
   int rc;
   try {
     rc = ptl::flatten_scene(*desc, flat, err);
-    if (rc == PT_OK) rc = ptl::check_fast_tree(*desc, flat, err);
+    // a description whose boxes are not nested is never walked through the fast tree (effective_mode), whose
+    // leaf boxes take those boxes at their word
+    if (rc == PT_OK && flat.n_unnested == 0) rc = ptl::check_fast_tree(*desc, flat, err);
   } catch (const std::bad_alloc &) {
     return fail(PT_ERR_NOMEM, "out of host memory while flattening the scene");
   }
@@ -818,6 +840,7 @@ int pt_scene_check(const PtSceneDesc *desc, PtSceneInfo *info) {
     info->n_wide_nodes = (uint32_t)flat.nodes.size(); info->max_depth = flat.max_depth;
     info->n_fast_nodes = (uint32_t)flat.nodes4.size(); info->fast_max_depth = flat.max_depth4;
     info->n_gates = (uint32_t)flat.gates.size();
+    info->boxes_nested = flat.n_unnested == 0 ? 1u : 0u;
   }
   return PT_OK;
 }
@@ -830,6 +853,8 @@ int pt_scene_info(const PtScene *s, PtSceneInfo *info) {
   info->n_wide_nodes = s->dev.n_nodes; info->max_depth = s->max_depth; info->device = (uint32_t)s->device;
   info->n_fast_nodes = s->dev.n_nodes4; info->fast_max_depth = s->max_depth4; info->n_gates = s->dev.n_gates;
   info->device_bytes = s->bytes;
+  info->boxes_nested = s->n_unnested == 0 ? 1u : 0u;
+  info->reserved = 0;
   return PT_OK;
 }
 
@@ -841,20 +866,30 @@ int pt_scene_count_stats(PtScene *s, int enable) {
   return PT_OK;
 }
 
+// `all_near`: the caller has looked at the origins (host arrays) and all of them are within near_limit(); the
+// exact launch for the far ones is then left out.
 static int trace_dev(PtScene *s, size_t n, const float *ox, const float *oy, const float *oz, const float *dx,
                      const float *dy, const float *dz, float *t, int32_t *tri, float *u, float *v, int mode,
-                     hipStream_t st) {
+                     hipStream_t st, bool all_near) {
   if (n == 0) return PT_OK;
   if (n > ((size_t)1 << 36)) return fail(PT_ERR_INVALID, "too many rays for one call");  // the work-queue head counts chunks of 64 in 32 bits
   if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   mode = effective_mode(s, mode);
   int rc = enter_stream(s, st);
   if (rc != PT_OK) return rc;
-  rc = with_mode(mode, [&](auto MM) -> int {
-    constexpr int M = decltype(MM)::value;
-    return s->count_stats ? launch_trace_api<M, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st)
-                          : launch_trace_api<M, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st);
-  });
+  auto go = [&](int m, RaySide side) -> int {
+    return with_mode(m, [&](auto MM) -> int {
+      constexpr int M = decltype(MM)::value;
+      return s->count_stats ? launch_trace_api<M, true>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st, side)
+                            : launch_trace_api<M, false>(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, st, side);
+    });
+  };
+  if (mode == PT_TRACE_EXACT || all_near) {
+    rc = go(mode, RaySide{SIDE_ALL, 0.0f});
+  } else {
+    rc = go(mode, RaySide{SIDE_NEAR, near_limit(s)});
+    if (rc == PT_OK) rc = go(PT_TRACE_EXACT, RaySide{SIDE_FAR, near_limit(s)});
+  }
   if (rc != PT_OK) return rc;
   return leave_stream(s, st);
 }
@@ -866,7 +901,7 @@ int pt_trace_closest_dev(PtScene *s, size_t n, const float *ox, const float *oy,
   if (n && (!ox || !oy || !oz || !dx || !dy || !dz || !t || !tri)) return fail(PT_ERR_INVALID, "null ray or result array");
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
-  return trace_dev(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, mode, (hipStream_t)stream);
+  return trace_dev(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, mode, (hipStream_t)stream, false);
 }
 
 static int read_stats4(PtScene *s, uint64_t out[4]) {
@@ -929,7 +964,8 @@ int pt_trace_closest(PtScene *s, size_t n, const float *ox, const float *oy, con
     for (int a = 0; a < 6 && e == hipSuccess; ++a) e = hipMemcpy(buf + a * m, src[a], k * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
     rc = trace_dev(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, buf + 6 * m,
-                   reinterpret_cast<int32_t *>(buf + 7 * m), buf + 8 * m, buf + 9 * m, mode, 0);
+                   reinterpret_cast<int32_t *>(buf + 7 * m), buf + 8 * m, buf + 9 * m, mode, 0,
+                   host_origins_within(src[0], src[1], src[2], k, near_limit(s)));
     if (rc != PT_OK) break;
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(t + off, buf + 6 * m, k * sizeof(float), hipMemcpyDeviceToHost);
@@ -965,9 +1001,17 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
     for (int a = 0; a < 6 && e == hipSuccess; ++a) e = hipMemcpy(buf + a * m, src[a], k * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
     uint8_t *dh = reinterpret_cast<uint8_t *>(buf + 6 * m);
-    rc = with_mode(mode, [&](auto MM) -> int {
-      return launch_any_api<decltype(MM)::value>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
-    });
+    auto go = [&](int md, RaySide side) -> int {
+      return with_mode(md, [&](auto MM) -> int {
+        return launch_any_api<decltype(MM)::value>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0, side);
+      });
+    };
+    if (mode == PT_TRACE_EXACT || host_origins_within(src[0], src[1], src[2], k, near_limit(s))) {
+      rc = go(mode, RaySide{SIDE_ALL, 0.0f});
+    } else {  // the pruning walk for the origins in its range, the exact walk for the others
+      rc = go(mode, RaySide{SIDE_NEAR, near_limit(s)});
+      if (rc == PT_OK) rc = go(PT_TRACE_EXACT, RaySide{SIDE_FAR, near_limit(s)});
+    }
     if (rc != PT_OK) break;
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(hit + off, dh, k, hipMemcpyDeviceToHost);
@@ -1001,8 +1045,18 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
     if (e != hipSuccess) { rc = fail(PT_ERR_DEVICE, std::string("copy of rays: ") + hipGetErrorString(e)); break; }
     int32_t *dh = reinterpret_cast<int32_t *>(buf + 6 * m);
     // HitData::hits is a property of the reference's trees: both pruning modes walk those
-    rc = (mode == PT_TRACE_EXACT || s->dev.n_ill != 0) ? launch_hits_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0)
-                                : launch_hits_api<PT_TRACE_FAST_BINARY>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0);
+    auto go = [&](bool exact, RaySide side) -> int {
+      return exact ? launch_hits_api<PT_TRACE_EXACT>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0, side)
+                   : launch_hits_api<PT_TRACE_FAST_BINARY>(s, k, buf, buf + m, buf + 2 * m, buf + 3 * m, buf + 4 * m, buf + 5 * m, dh, 0, side);
+    };
+    if (mode == PT_TRACE_EXACT || s->dev.n_ill != 0) {
+      rc = go(true, RaySide{SIDE_ALL, 0.0f});
+    } else if (host_origins_within(src[0], src[1], src[2], k, near_limit(s))) {
+      rc = go(false, RaySide{SIDE_ALL, 0.0f});
+    } else {
+      rc = go(false, RaySide{SIDE_NEAR, near_limit(s)});
+      if (rc == PT_OK) rc = go(true, RaySide{SIDE_FAR, near_limit(s)});
+    }
     if (rc != PT_OK) break;
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(hits + off, dh, k * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -1033,8 +1087,9 @@ int pt_camera_rays(const PtCamera *cam, int W, int H, int device, float *dir_xyz
 
 // The frame loop shared by pt_render_dev and pt_render_dev_static: `batch` samples per pixel in flight
 // together, in the workspace and counter block s->aw / s->acnt point at.
+// `mean`: accum is the reference's Camera::pixels (a running mean of radiance * 255) instead of radiance sums.
 static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t spp_begin, uint32_t spp_count,
-                          uint32_t batch, float *accum, PtCounters &c, hipStream_t st) {
+                          uint32_t batch, float *accum, PtCounters &c, hipStream_t st, bool mean) {
   int rc = PT_OK;
   Workspace &w = *s->aw;
   uint32_t *cnt = s->acnt;
@@ -1122,7 +1177,8 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
       n = s->h_cnt[0];
     }
     if (prof) HIP_TRY(hipEventRecord(s->ev[0], st));
-    hipLaunchKernelGGL(k_resolve, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, w.rad, accum);
+    if (mean) hipLaunchKernelGGL(k_resolve_mean, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, F.sample0, w.rad, accum);
+    else hipLaunchKernelGGL(k_resolve, dim3((F.P + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F.P, sb, w.rad, accum);
     HIP_TRY(hipGetLastError());
     if (prof) {
       HIP_TRY(hipEventRecord(s->ev[3], st));
@@ -1146,14 +1202,25 @@ static uint64_t bytes_per_path(const PtScene *s, bool split) {
   return (uint64_t)(kWsArrays * sizeof(float)) + 2 + (split ? 12ull + 25ull * s->dev.n_lights : 0ull);
 }
 
+// Paths the static device buffer holds for this scene: 256 bytes of counters, then the workspace.
+static const uint64_t kStaticRoom = PT_STATIC_SCRATCH_BYTES - 256 - 4096;  // slack for the alignment of the parts
+static uint64_t static_capacity(const PtScene *s, bool split) {
+  uint64_t cap = kStaticRoom / (bytes_per_path(s, split) + 1);
+  cap &= ~63ull;
+  // ws_*_bytes round up in places: shrink until the two parts fit
+  while (cap >= 64 && ws_main_bytes(cap) + 256 + ws_shadow_bytes(cap, s->dev.n_lights, split) > kStaticRoom) cap -= 64;
+  return cap;
+}
+
 static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
                            uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, hipStream_t st,
-                           bool use_static) {
+                           bool use_static, bool mean = false) {
   FrameDev F;
   int rc = make_frame(cam, W, H, seed, opt, s->dev.n_lights, F);
   if (rc != PT_OK) return rc;
   PtOptions o;
   if (opt) o = *opt; else pt_options_default(&o);
+  if (mean && F.stride != 1) return fail(PT_ERR_INVALID, "the running mean is defined over consecutive passes: spp_stride must be 1");
   if (!valid_mode(o.trace_mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   o.trace_mode = effective_mode(s, o.trace_mode);
   if (o.trace_mode != PT_TRACE_EXACT && cam) {
@@ -1161,7 +1228,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
     // every path of a frame starts at the camera (its later vertices lie on the scene)
     float far = 0;
     for (int k = 0; k < 3; ++k) far = std::fmax(far, std::fabs(cam->origin[k]));
-    if (!(far <= 16.0f * s->max_abs_coord)) o.trace_mode = PT_TRACE_EXACT;
+    if (!(far <= near_limit(s))) o.trace_mode = PT_TRACE_EXACT;
   }
   const bool split = plan_of(s, o.trace_mode).split;
   PtCounters c;
@@ -1177,11 +1244,8 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
     // everything comes out of the static device buffer: 256 bytes of counters, then the workspace
     unsigned char *base = static_scratch(s->device);
     if (!base) return fail(PT_ERR_DEVICE, "the static device buffer was not set up on this device");
-    const uint64_t room = PT_STATIC_SCRATCH_BYTES - 256 - 4096;  // slack for the alignment of the parts
-    uint64_t cap = room / (per_path + 1);
-    cap &= ~63ull;
-    // ws_*_bytes round up in places: shrink until the two parts fit
-    while (cap >= 64 && ws_main_bytes(cap) + 256 + ws_shadow_bytes(cap, s->dev.n_lights, split) > room) cap -= 64;
+    const uint64_t room = kStaticRoom;
+    const uint64_t cap = static_capacity(s, split);
     if (cap < F.P) {
       char msg[256];
       std::snprintf(msg, sizeof(msg), "pt_render_dev_static: a %dx%d frame of this scene needs %llu bytes of workspace per sample "
@@ -1229,7 +1293,17 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
     s->acnt = s->d_cnt;
   }
   rc = enter_stream(s, st);
-  if (rc == PT_OK) rc = render_batches(s, F, o, spp_begin, spp_count, batch, accum, c, st);
+  if (rc == PT_OK && use_static) {
+    // the previous user of this GPU's static buffer, whichever scene and stream it was (an event that was
+    // never recorded counts as complete)
+    const hipError_t e = hipStreamWaitEvent(st, g_scratch_last[s->device], 0);
+    if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+  }
+  if (rc == PT_OK) rc = render_batches(s, F, o, spp_begin, spp_count, batch, accum, c, st, mean);
+  if (rc == PT_OK && use_static) {
+    const hipError_t e = hipEventRecord(g_scratch_last[s->device], st);
+    if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("hipEventRecord: ") + hipGetErrorString(e));
+  }
   if (rc == PT_OK) rc = leave_stream(s, st);
   s->aw = &s->ws;
   s->acnt = s->d_cnt;
@@ -1246,6 +1320,14 @@ int pt_render_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_be
   return render_dev_impl(s, cam, W, H, spp_begin, spp_count, seed, opt, accum, counters, (hipStream_t)stream, false);
 }
 
+int pt_render_mean_dev(PtScene *s, const PtCamera *cam, int W, int H, uint32_t pass_begin, uint32_t pass_count,
+                       uint64_t seed, const PtOptions *opt, float *pixels, PtCounters *counters, void *stream) {
+  if (!s || !pixels) return fail(PT_ERR_INVALID, "null scene or pixels");
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(s->device));
+  return render_dev_impl(s, cam, W, H, pass_begin, pass_count, seed, opt, pixels, counters, (hipStream_t)stream, false, true);
+}
+
 int pt_render_dev_static(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count,
                          uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters, void *stream) {
   if (!s || !accum) return fail(PT_ERR_INVALID, "null scene or accumulator");
@@ -1255,6 +1337,11 @@ int pt_render_dev_static(PtScene *s, const PtCamera *cam, int W, int H, uint32_t
 }
 
 uint64_t pt_static_scratch_bytes(void) { return PT_STATIC_SCRATCH_BYTES; }
+
+uint64_t pt_static_max_pixels(const PtScene *s, int trace_mode) {
+  if (!s || !valid_mode(trace_mode)) return 0;
+  return static_capacity(s, plan_of(s, effective_mode(s, trace_mode)).split);
+}
 
 int pt_render(PtScene *s, const PtCamera *cam, int W, int H, uint32_t spp_begin, uint32_t spp_count, uint64_t seed,
               const PtOptions *opt, float *accum, PtCounters *counters) {
@@ -1329,6 +1416,16 @@ static int rccl_comms(const std::vector<int> &devices, std::vector<ncclComm_t> &
   return PT_OK;
 }
 
+int pt_shard_samples(uint32_t spp_begin, uint32_t spp_count, uint32_t spp_stride, uint32_t shard, uint32_t n_shards,
+                     uint32_t *begin, uint32_t *count, uint32_t *stride) {
+  if (n_shards == 0 || shard >= n_shards || !begin || !count || !stride) return fail(PT_ERR_INVALID, "bad shard or null output");
+  const uint32_t st = spp_stride ? spp_stride : 1;
+  *begin = spp_begin + shard * st;
+  *count = spp_count > shard ? (spp_count - shard + n_shards - 1) / n_shards : 0;
+  *stride = st * n_shards;
+  return PT_OK;
+}
+
 int pt_render_multi(PtScene *const *scenes, int n, const PtCamera *cam, int W, int H, uint32_t spp_begin,
                     uint32_t spp_count, uint64_t seed, const PtOptions *opt, float *accum, PtCounters *counters) {
   if (!scenes || n <= 0 || !accum) return fail(PT_ERR_INVALID, "null scenes or accumulator");
@@ -1369,9 +1466,9 @@ int pt_render_multi(PtScene *const *scenes, int n, const PtCamera *cam, int W, i
       return;
     }
     PtOptions og = o;
-    og.spp_stride = stride * (uint32_t)n;
-    const uint32_t mine = spp_count > (uint32_t)g ? (spp_count - (uint32_t)g + (uint32_t)n - 1) / (uint32_t)n : 0;
-    rcs[g] = pt_render_dev(scenes[g], cam, W, H, spp_begin + (uint32_t)g * stride, mine, seed, &og, bufs[g], &cs[g], nullptr);
+    uint32_t first = 0, mine = 0;
+    (void)pt_shard_samples(spp_begin, spp_count, stride, (uint32_t)g, (uint32_t)n, &first, &mine, &og.spp_stride);
+    rcs[g] = pt_render_dev(scenes[g], cam, W, H, first, mine, seed, &og, bufs[g], &cs[g], nullptr);
     if (rcs[g] != PT_OK) errs[g] = g_err;
     else if ((e = hipDeviceSynchronize()) != hipSuccess) {
       rcs[g] = PT_ERR_DEVICE;
@@ -1423,6 +1520,76 @@ int pt_render_multi(PtScene *const *scenes, int n, const PtCamera *cam, int W, i
       if (cs[g].bounce_passes > counters->bounce_passes) counters->bounce_passes = cs[g].bounce_passes;
     }
   }
+  return PT_OK;
+}
+
+int pt_resolve_dev(const float *sum_dev, size_t n, uint32_t spp, float *pixels_dev, int device, void *stream) {
+  if (!sum_dev || !pixels_dev || spp == 0) return fail(PT_ERR_INVALID, "null array or spp == 0");
+  if (n == 0) return PT_OK;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_resolve_pixels, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, (float)spp,
+                     sum_dev, pixels_dev);
+  HIP_TRY(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_resolve_display_dev(const float *sum_dev, size_t n_pixels, uint32_t spp, uint8_t *rgb8_dev, int device, void *stream) {
+  if (!sum_dev || !rgb8_dev || spp == 0) return fail(PT_ERR_INVALID, "null array or spp == 0");
+  if (n_pixels == 0) return PT_OK;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  const size_t n = 3 * n_pixels;
+  hipLaunchKernelGGL(k_resolve_display<true>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, (float)spp,
+                     sum_dev, rgb8_dev);
+  HIP_TRY(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_display_dev(const float *pixels_dev, size_t n_pixels, uint8_t *rgb8_dev, int device, void *stream) {
+  if (!pixels_dev || !rgb8_dev) return fail(PT_ERR_INVALID, "null array");
+  if (n_pixels == 0) return PT_OK;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  const size_t n = 3 * n_pixels;
+  hipLaunchKernelGGL(k_resolve_display<false>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, 1.0f,
+                     pixels_dev, rgb8_dev);
+  HIP_TRY(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_device_alloc(int device, size_t bytes, void **out) {
+  if (!out) return fail(PT_ERR_INVALID, "null output");
+  *out = nullptr;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+  HIP_TRY(hipMemset(*out, 0, bytes ? bytes : 16));
+  return PT_OK;
+}
+
+int pt_device_free(int device, void *ptr) {
+  if (!ptr) return PT_OK;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(ptr));
+  return PT_OK;
+}
+
+int pt_device_clear(int device, void *ptr, size_t bytes, void *stream) {
+  if (!ptr) return fail(PT_ERR_INVALID, "null pointer");
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream));
+  return PT_OK;
+}
+
+int pt_device_read(int device, void *dst_host, const void *src_dev, size_t bytes, void *stream) {
+  if (!dst_host || !src_dev) return fail(PT_ERR_INVALID, "null pointer");
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return PT_OK;
 }
 

@@ -428,11 +428,29 @@ __global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan,
   }
 }
 
+// Which of a caller's rays a launch of the ray-query kernels walks.  The pruning walks are exact for origins
+// within `limit` of the world origin (16 times the scene's largest coordinate: their margins are relative to
+// that coordinate, and the rounding error of a box test grows with the origin's distance), so a query in a
+// pruning mode is two launches: the pruning walk for the rays inside that range (SIDE_NEAR) and the exact walk
+// for the others (SIDE_FAR, which includes origins that are not finite).  A ray the launch leaves out costs it
+// the read of its origin.
+enum : int { SIDE_ALL = 0, SIDE_NEAR = 1, SIDE_FAR = 2 };
+struct RaySide {
+  int side;
+  float limit;
+  __device__ __forceinline__ bool takes(V3 o) const {
+    if (side == SIDE_ALL) return true;
+    const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= limit;  // false for NaN
+    return side == SIDE_NEAR ? near : !near;
+  }
+};
+
 template <int MODE, int BLOCK, bool COUNT, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
                                                      const float *oy, const float *oz, const float *dx,
                                                      const float *dy, const float *dz, float *t, int32_t *tri,
-                                                     float *u, float *v, uint32_t *head, unsigned long long *stats) {
+                                                     float *u, float *v, uint32_t *head, unsigned long long *stats,
+                                                     RaySide side) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
@@ -440,6 +458,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, u
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
         o = mk(ox[i], oy[i], oz[i]);
+        if (!side.takes(o)) return false;
         d = mk(dx[i], dy[i], dz[i]);
         return true;
       },
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_api(SceneDev S, LdsPlan plan, u
 template <int MODE, int BLOCK, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
                                                    const float *oy, const float *oz, const float *dx, const float *dy,
-                                                   const float *dz, uint8_t *hit, uint32_t *head) {
+                                                   const float *dz, uint8_t *hit, uint32_t *head, RaySide side) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
@@ -468,6 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_any_api(SceneDev S, LdsPlan plan, uin
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
         o = mk(ox[i], oy[i], oz[i]);
+        if (!side.takes(o)) return false;
         d = mk(dx[i], dy[i], dz[i]);
         return true;
       },
@@ -517,7 +537,7 @@ template <int MODE, int BLOCK, bool RES>
 __global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, uint32_t kRun, size_t n, const float *ox,
                                                     const float *oy, const float *oz, const float *dx, const float *dy,
                                                     const float *dz, const uint8_t *levels, int32_t *hits,
-                                                    uint32_t *head) {
+                                                    uint32_t *head, RaySide side) {
   uint32_t stk;
   const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
@@ -525,6 +545,7 @@ __global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, ui
       S, C, stk, n, kRun, head, nb, nt,
       [&](uint64_t i, V3 &o, V3 &d) {
         o = mk(ox[i], oy[i], oz[i]);
+        if (!side.takes(o)) return false;
         d = mk(dx[i], dy[i], dz[i]);
         return true;
       },
@@ -1060,6 +1081,42 @@ __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t P, uint32_t S, RadD
     r += x.x; g += x.y; b += x.z;
   }
   accum[3 * (size_t)p + 0] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
+}
+
+// The reference's own accumulator (camera.cpp:188-190): pixels = (i * pixels + radiance * 255) / (i + 1) after
+// pass i, every operation in float as vector_'s operators perform it (math.cpp:168-183), the batch's samples
+// applied in pass order.  `first` is the pass index of the batch's first sample.
+__global__ __launch_bounds__(kBlock) void k_resolve_mean(uint32_t P, uint32_t S, uint32_t first, RadDev rad, float *pixels) {
+  const float4 *R = rad.R();
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  float r = pixels[3 * (size_t)p + 0], g = pixels[3 * (size_t)p + 1], b = pixels[3 * (size_t)p + 2];
+  for (uint32_t s = 0; s < S; ++s) {
+    const float4 x = R[(size_t)s * P + p];
+    const float i = (float)(first + s), n1 = (float)(first + s + 1u);
+    r = (i * r + x.x * 255.0f) / n1;
+    g = (i * g + x.y * 255.0f) / n1;
+    b = (i * b + x.z * 255.0f) / n1;
+  }
+  pixels[3 * (size_t)p + 0] = r; pixels[3 * (size_t)p + 1] = g; pixels[3 * (size_t)p + 2] = b;
+}
+
+// Camera::pixels from the sums: pixels = sum / spp * 255 (the running mean of camera.cpp:188-190, as a sum).
+__global__ __launch_bounds__(kBlock) void k_resolve_pixels(size_t n, float spp, const float *sum, float *pixels) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) pixels[i] = sum[i] / spp * 255.0f;
+}
+
+// The display conversion of the GUI callback (main.cpp:43-47): norm(i) = std::clamp((int)i, 0, 255) with the
+// float widened to double first (exact), i.e. truncation toward zero as the x86-64 build performs it, where a
+// value out of int range or NaN converts to INT_MIN and so clamps to 0.  One RGB byte triple per pixel.
+// FROM_SUMS: the input holds radiance sums of `spp` samples; otherwise it holds Camera::pixels itself.
+template <bool FROM_SUMS>
+__global__ __launch_bounds__(kBlock) void k_resolve_display(size_t n, float spp, const float *in, uint8_t *rgb) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int v = cvt_int_x86(FROM_SUMS ? in[i] / spp * 255.0f : in[i]);
+  rgb[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
 #endif

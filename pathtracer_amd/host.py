@@ -43,6 +43,8 @@ def lib():
         L.pth_point_towards.restype = None
         L.pth_camera_render.argtypes = [C.c_void_p, C.POINTER(api.PtCamera), C.POINTER(api.PtOptions), C.c_int, C.c_int,
                                         C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(api.PtCounters), _CB, C.c_int]
+        L.pth_camera_render_display.argtypes = [C.c_void_p, C.POINTER(api.PtCamera), C.POINTER(api.PtOptions), C.c_int, C.c_int,
+                                                C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, _CB, C.c_int]
         L.pth_save_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
@@ -155,6 +157,24 @@ class Scene:
         if rc != 0:
             raise api.PtError(rc, lib().pth_last_error().decode())
         return pixels, cnt
+
+
+def _render_display(self, cam, W, H, samples, seed=0, opt=None, device=0, callback=None, every=1):
+    """Camera::render with the GUI callback's display conversion (main.cpp:43-47) done on the device: returns
+    (rgb[H,W,3] uint8 = clamp((int)pixels, 0, 255), pixels[H,W,3]).  `callback(rgb)` sees the bytes after every
+    `every` passes."""
+    rgb = np.zeros((H, W, 3), np.uint8)
+    pixels = np.zeros((H, W, 3), np.float32)
+    o = opt if opt is not None else api.make_options()
+    cb = _CB(lambda: callback(rgb.copy())) if callback else _CB()
+    rc = lib().pth_camera_render_display(self._h, C.byref(cam), C.byref(o), W, H, samples, seed, device, _p(rgb),
+                                         _p(pixels), cb, every)
+    if rc != 0:
+        raise api.PtError(rc, lib().pth_last_error().decode())
+    return rgb, pixels
+
+
+Scene.render_display = _render_display
 
 
 def load_image(path):

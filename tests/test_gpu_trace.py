@@ -357,3 +357,101 @@ def test_random_triangle_soups_bit_exact(api, seed):
             check_equal(ref, ds.trace_closest(ro, rd, mode), "soup%d/%s/mode%d" % (seed, label, mode))
             assert ((ref["tri"] >= 0) == ds.trace_any(ro, rd, mode)).all(), "soup%d/%s any-hit mode %d" % (seed, label, mode)
     ds.close()
+
+
+@pytest.mark.parametrize("name", ["box40", "atrium_small", "blob_small"])
+def test_origins_far_from_the_scene_match_in_every_mode(api, name):
+    """The pruning walks carry margins for origins near the scene only (the rounding error of a box test grows
+    with the origin's distance).  The ray queries therefore walk every ray whose origin lies beyond 16 times the
+    scene's largest coordinate exactly, ray by ray, whatever mode was asked for: rays aimed at the scene from
+    1 to 100 000 scene extents away, mixed in one call, equal Scene::castray in all three modes (closest hit,
+    any hit and HitData::hits), through the host-pointer and the device-pointer entry points."""
+    import torch
+    w, ds = util.world(name), dev_scene(api, name)
+    verts = w.export()["tri_verts"].reshape(-1, 3)
+    rng = np.random.default_rng(4)
+    n = 20000
+    os_, ds_ = [], []
+    for far in (1, 10, 100, 1000, 10000, 100000):
+        o = (rng.standard_normal((n, 3)) * far * 3 + np.float32([0, 0, 2])).astype(np.float32)
+        tgt = verts[rng.integers(0, len(verts), n)] + rng.normal(0, 0.05, (n, 3))
+        os_.append(o)
+        ds_.append((tgt - o).astype(np.float32))
+    o, d = np.concatenate(os_), np.concatenate(ds_)
+    perm = rng.permutation(len(o))          # near and far origins side by side in every wave
+    o, d = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm])
+    ref = w.castray(o, d)
+    assert (ref["tri"] >= 0).mean() > 0.3
+    ref_hits = w.castray(o, d, want_hits=True)["hits"]
+    for mode in (api.PT_TRACE_EXACT, api.PT_TRACE_FAST, api.PT_TRACE_FAST_BINARY):
+        check_equal(ref, ds.trace_closest(o, d, mode), "%s/far origins/mode %d" % (name, mode))
+        assert ((ref["tri"] >= 0) == ds.trace_any(o, d, mode)).all()
+        assert (ds.trace_hits(o, d, mode) == ref_hits).all()
+    # device pointers: both launches are enqueued without looking at the origins
+    dev = torch.device("cuda", 0)
+    cols = [torch.from_numpy(np.ascontiguousarray(a[:, i])).to(dev) for a in (o, d) for i in range(3)]
+    t = torch.empty(len(o), dtype=torch.float32, device=dev)
+    tri = torch.empty(len(o), dtype=torch.int32, device=dev)
+    u = torch.empty_like(t)
+    v = torch.empty_like(t)
+    ds.trace_closest_dev(len(o), [c.data_ptr() for c in cols], [t.data_ptr(), tri.data_ptr(), u.data_ptr(), v.data_ptr()],
+                         mode=api.PT_TRACE_FAST)
+    torch.cuda.synchronize()
+    check_equal(ref, dict(t=t.cpu().numpy(), tri=tri.cpu().numpy(), u=u.cpu().numpy(), v=v.cpu().numpy()),
+                "%s/far origins/device pointers" % name)
+
+
+def test_description_with_boxes_that_are_not_nested_is_walked_exactly(api):
+    """PT_TRACE_FAST tests the lowest internal box above a triangle in place of all of them; that is the
+    reference's test only for nested boxes.  A description with an inner box refitted too tight (the exact walk
+    then loses the triangles that stick out, as the reference would with that tree) is flagged at upload and
+    walked exactly in every mode: same hits as PT_TRACE_EXACT, and they differ from the intact scene's."""
+    good = util.world("atrium_small").export()
+    nodes, off = good["blas_nodes"], good["blas_node_offset"]
+    e = {k: v.copy() for k, v in good.items()}
+    changed = 0
+    for m in range(len(off) - 1):
+        if off[m + 1] - off[m] >= 5 and nodes[off[m]]["count"] == 0:
+            lo, hi = nodes["bmin"][off[m]].copy(), nodes["bmax"][off[m]].copy()
+            e["blas_nodes"]["bmax"][off[m]] = lo + (hi - lo) * 0.5
+            changed += 1
+    assert changed
+    ds_bad, ds_good = api.DeviceScene(e), dev_scene(api, "atrium_small")
+    assert ds_bad.info["boxes_nested"] == 0 and ds_good.info["boxes_nested"] == 1
+    o, d = util.random_rays(60000, 8)
+    exact = ds_bad.trace_closest(o, d, api.PT_TRACE_EXACT)
+    for mode in (api.PT_TRACE_FAST, api.PT_TRACE_FAST_BINARY):
+        check_equal(exact, ds_bad.trace_closest(o, d, mode), "not nested/mode %d" % mode)
+        assert ((exact["tri"] >= 0) == ds_bad.trace_any(o, d, mode)).all()
+    intact = ds_good.trace_closest(o, d, api.PT_TRACE_EXACT)
+    assert (intact["tri"] != exact["tri"]).mean() > 0.01      # the shrunk boxes do change what the reference's walk finds
+    cam = api.make_camera(vw=16, vh=9)
+    a, _ = ds_bad.render(cam, 96, 54, 3, seed=2, opt=api.make_options(trace_mode=api.PT_TRACE_EXACT))
+    b, _ = ds_bad.render(cam, 96, 54, 3, seed=2, opt=api.make_options(trace_mode=api.PT_TRACE_FAST))
+    assert (util.bits(a) == util.bits(b)).all()
+    ds_bad.close()
+
+
+def test_hit_with_a_nan_distance_is_never_recorded(api):
+    """Known deviation, pinned: Triangle::intersect can return a hit whose t is NaN (a determinant so small that
+    its reciprocal overflows, times an exactly zero numerator: inf * 0).  In the reference what becomes of it
+    depends on where the triangle sits in its leaf and tree (every comparison with NaN is false); here such a
+    hit is never recorded, in any mode: the ray's answer is that of the scene without that triangle."""
+    from pathtracer_amd import scenes
+    meshes, mats = scenes.box_room(10)
+    tiny = np.float32([[0, 0, 0], [1e-20, 0, 0], [0, 1e-20, 0]])
+    meshes2 = list(meshes) + [(tiny, np.uint32([[0, 1, 2]]), 0)]
+    w0, w1 = O.World.from_meshes(meshes, mats), O.World.from_meshes(meshes2, mats)
+    o = np.float32([[0, 0, -0.5], [0, 0, 0.5], [0.25, 0, -0.5]])
+    d = np.float32([[0, 0, 1], [0, 0, -1], [0, 0, 1]])
+    # the oracle's Triangle::intersect does report the NaN hit for the first two rays
+    one = O.World.from_meshes([(tiny, np.uint32([[0, 1, 2]]), 0)], mats)
+    r = one.castray(o, d)
+    assert np.isnan(r["t"][:2]).all() and (r["tri"][:2] == 0).all() and r["tri"][2] == -1
+    ds0, ds1 = api.DeviceScene(w0.export()), api.DeviceScene(w1.export())
+    for mode in (api.PT_TRACE_EXACT, api.PT_TRACE_FAST, api.PT_TRACE_FAST_BINARY):
+        a, b = ds0.trace_closest(o, d, mode), ds1.trace_closest(o, d, mode)
+        assert (util.bits(a["t"]) == util.bits(b["t"])).all() and (a["tri"] == b["tri"]).all()
+        assert not np.isnan(b["t"]).any() and b["tri"][0] >= 0      # the second ray leaves through the room's open side
+    ds0.close()
+    ds1.close()

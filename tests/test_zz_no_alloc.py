@@ -87,4 +87,39 @@ def test_static_entry_point_rejects_frames_beyond_its_buffer(api):
     assert api.lib().pt_static_scratch_bytes() == 64 << 20
     torch.cuda.synchronize()
     assert float(acc.sum()) == 0.0
+    # the limit the library states is the limit it enforces
+    cap = ds.static_max_pixels()
+    assert 300_000 < cap < 400_000
+    small = torch.zeros(3 * cap, dtype=torch.float32, device=torch.device("cuda", 0))
+    side = int(cap ** 0.5)
+    ds.render_dev_static(cam, side, side, 1, small.data_ptr())              # just inside
+    with pytest.raises(api.PtError):
+        ds.render_dev_static(cam, cap + 64, 1, 1, small.data_ptr())         # just outside
     ds.close()
+
+
+def test_static_calls_from_two_scenes_on_two_streams_are_ordered(api):
+    """The static buffer is one per GPU.  Calls that name different scenes and different streams are ordered
+    on the device by the library (an event per GPU), so each still equals pt_render_dev bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    names = ("box", "atrium_small")
+    scenes_ = [api.DeviceScene(util.world(n).export()) for n in names]
+    cam = api.make_camera(vw=16, vh=9)
+    W, H, spp = 256, 144, 3
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    want = []
+    for ds in scenes_:
+        a = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+        ds.render_dev(cam, W, H, spp, a.data_ptr(), seed=5)
+        torch.cuda.synchronize()
+        want.append(a.cpu().numpy())
+    outs = [torch.zeros(H * W * 3, dtype=torch.float32, device=dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    for k in range(4):            # box, atrium, box, atrium: alternating scenes and streams, no host wait between
+        scenes_[k % 2].render_dev_static(cam, W, H, spp, outs[k].data_ptr(), seed=5, stream=streams[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert (outs[k].cpu().numpy().view(np.uint32) == want[k % 2].view(np.uint32)).all(), k
+    for ds in scenes_:
+        ds.close()
