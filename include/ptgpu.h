@@ -184,6 +184,7 @@ typedef struct PtProfile {
   uint64_t shade_launches;
   double tail_ms;         /* the kernel that follows the last paths of a batch to their ends */
   uint64_t tail_launches;
+  uint64_t trace_rays;    /* rays walked by the closest-hit kernel's launches (the tail kernel's are not among them) */
 } PtProfile;
 
 const char *pt_last_error(void);

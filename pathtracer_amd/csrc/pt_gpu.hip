@@ -1169,6 +1169,7 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
         if ((rc = elapsed(1, 2, s->prof.shade_ms)) != PT_OK) return rc;
         s->prof.trace_launches += 1;
         s->prof.shade_launches += 1;
+        s->prof.trace_rays += n;
       }
       cur ^= 1;
       c.rays_closest += n;
@@ -1273,7 +1274,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const uint64_t have = s->ws.cap ? ws_main_bytes(ws_stride(s->ws.cap)) + ws_shadow_bytes(ws_stride(s->ws.cap), s->dev.n_lights, s->ws.has_shadow) : 0;
-        const uint64_t fit = ((uint64_t)free_b / 4 + have) / per_path;
+        const uint64_t fit = ((uint64_t)free_b + have) / 4 / per_path;  // (a quarter of the free memory plus the workspace itself grew the batch with every call)
         if (fit < target) target = fit;
       }
       if (s->ws.cap > target) target = s->ws.cap;  // a workspace that exists is used in full
@@ -1431,10 +1432,21 @@ int pt_render_multi(PtScene *const *scenes, int n, const PtCamera *cam, int W, i
   if (!scenes || n <= 0 || !accum) return fail(PT_ERR_INVALID, "null scenes or accumulator");
   if (W <= 0 || H <= 0 || (uint64_t)W * (uint64_t)H > (1ull << 28)) return fail(PT_ERR_INVALID, "bad image size");
   std::vector<int> devices;
+  // PT_MULTI_SHARE_DEVICE=1 (a rehearsal switch for boxes with one GPU): several of the scenes may live on one
+  // device.  Threads, sample dealing and the merge of the counters run as they do on several GPUs; the
+  // accumulators are then added up by a kernel, because RCCL takes each device once per communicator.
+  const char *share_env = std::getenv("PT_MULTI_SHARE_DEVICE");
+  const bool may_share = share_env && std::atoi(share_env) != 0;
+  bool shared = false;
   for (int g = 0; g < n; ++g) {
     if (!scenes[g]) return fail(PT_ERR_INVALID, "null scene");
+    for (int h = 0; h < g; ++h)
+      if (scenes[h] == scenes[g]) return fail(PT_ERR_INVALID, "the same scene object twice");
     for (int d : devices)
-      if (d == scenes[g]->device) return fail(PT_ERR_INVALID, "two scenes on one device");
+      if (d == scenes[g]->device) {
+        if (!may_share) return fail(PT_ERR_INVALID, "two scenes on one device");
+        shared = true;
+      }
     devices.push_back(scenes[g]->device);
   }
   if (n == 1) return pt_render(scenes[0], cam, W, H, spp_begin, spp_count, seed, opt, accum, counters);
@@ -1486,7 +1498,16 @@ int pt_render_multi(PtScene *const *scenes, int n, const PtCamera *cam, int W, i
       cleanup();
       return fail(rcs[g], "device " + std::to_string(devices[g]) + ": " + errs[g]);
     }
-  {
+  if (shared) {
+    for (int g = 1; g < n; ++g) {
+      if (devices[g] != devices[0]) { cleanup(); return fail(PT_ERR_INVALID, "PT_MULTI_SHARE_DEVICE: all scenes must be on one device"); }
+    }
+    (void)hipSetDevice(devices[0]);
+    for (int g = 1; g < n; ++g)
+      hipLaunchKernelGGL(k_add_into, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, count, bufs[0], bufs[g]);
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { cleanup(); return fail(PT_ERR_DEVICE, std::string("merge: ") + hipGetErrorString(e)); }
+  } else {
     std::vector<ncclComm_t> comms;
     int rc = rccl_comms(devices, comms);
     if (rc != PT_OK) { cleanup(); return rc; }

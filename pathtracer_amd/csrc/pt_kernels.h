@@ -1101,6 +1101,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve_mean(uint32_t P, uint32_t S,
   pixels[3 * (size_t)p + 0] = r; pixels[3 * (size_t)p + 1] = g; pixels[3 * (size_t)p + 2] = b;
 }
 
+// dst += src (merging per-device accumulators that happen to live on one device).
+__global__ __launch_bounds__(kBlock) void k_add_into(size_t n, float *dst, const float *src) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
 // Camera::pixels from the sums: pixels = sum / spp * 255 (the running mean of camera.cpp:188-190, as a sum).
 __global__ __launch_bounds__(kBlock) void k_resolve_pixels(size_t n, float spp, const float *sum, float *pixels) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;

@@ -208,6 +208,32 @@ def test_render_multi_on_one_device_equals_render(api):
     ds.close()
 
 
+def test_render_multi_rehearsed_on_one_device(api, monkeypatch):
+    """The n > 1 branch of pt_render_multi on a box with one GPU: with PT_MULTI_SHARE_DEVICE=1 three copies of the
+    scene on device 0 stand in for three devices.  One host thread per copy, the samples dealt round-robin,
+    counters merged; only the all-reduce is replaced (RCCL takes a device once per communicator) by an on-device
+    sum.  The frame is the one-device frame up to the order of the float additions, ray counts add up exactly,
+    and without the switch two scenes on one device are still refused."""
+    e = util.world("atrium_small").export()
+    copies = [api.DeviceScene(e) for _ in range(3)]
+    cam = api.make_camera(vw=16, vh=9)
+    one, c1 = copies[0].render(cam, 160, 90, 10, seed=6)
+    with pytest.raises(api.PtError):
+        api.render_multi(copies, cam, 160, 90, 10, seed=6)
+    monkeypatch.setenv("PT_MULTI_SHARE_DEVICE", "1")
+    many, cn = api.render_multi(copies, cam, 160, 90, 10, seed=6)
+    np.testing.assert_allclose(many, one, rtol=2e-5, atol=1e-6)
+    assert (cn.paths, cn.rays_closest, cn.rays_shadow) == (c1.paths, c1.rays_closest, c1.rays_shadow)
+    # fewer samples than copies: the idle copies add nothing
+    a, _ = copies[0].render(cam, 160, 90, 2, seed=6)
+    b, cb = api.render_multi(copies, cam, 160, 90, 2, seed=6)
+    np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-6)
+    with pytest.raises(api.PtError):
+        api.render_multi([copies[0], copies[0]], cam, 160, 90, 2)     # the same object twice
+    for s in copies:
+        s.close()
+
+
 def test_render_multi_over_all_devices(api):
     """The samples dealt over every visible device and merged by one RCCL all-reduce: the frame one device
     renders, up to the order of the float additions; ray counts add up exactly."""

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 template <int REC, int PIECES>
@@ -57,7 +58,13 @@ static void run(size_t table_bytes, int waves_per_simd) {
   (void)hipFree(table); (void)hipFree(out);
 }
 
-int main() {
+int main(int argc, char **argv) {
+  if (argc == 4) {  // one case only (for counter passes): table MB, record bytes (128 or 64), waves per SIMD
+    const size_t mb = (size_t)atol(argv[1]);
+    const int w = atoi(argv[3]);
+    if (atoi(argv[2]) == 128) run<128, 7>(mb << 20, w); else run<64, 4>(mb << 20, w);
+    return 0;
+  }
   for (size_t mb : {8, 24, 200, 600}) {
     for (int w : {1, 2, 4, 8}) {
       run<128, 7>(mb << 20, w);
