@@ -312,7 +312,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
           RayState st;
           walk_init<MODE, WANT_N>(S, C, st, o, d);
           do {
-            walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, S.quorum);
+            walk_step<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, S.quorum);
           } while (__ballot(!st.done()) != 0);
           retire(i, st);
         }
@@ -330,6 +330,9 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
     RayState st;
     st.live = false;
     st.pend = 0;
+    st.verify = false;
+    st.gated = false;
+    st.gate = ptl::NO_GATE;
     for (;;) {
       const unsigned long long m_busy = __ballot(busy);
       const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
@@ -371,7 +374,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
         n_idle_now = 64u - (uint32_t)__popcll(m_now);
       }
       // the quorum for testing parked leaves counts against the lanes that have a ray at all
-      walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, ((64u - n_idle_now) * S.quorum) >> 6);
+      walk_step<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, ((64u - n_idle_now) * S.quorum) >> 6);
       if (busy && st.done()) busy = false;
     }
   }
@@ -400,8 +403,13 @@ __device__ __forceinline__ bool survives(const SceneDev &S, const PathFrame &F, 
 // vertex and leaves that as one byte per ray in `alive_out`, from which k_scan_local forms the
 // 64-bit mask of each chunk, so that the survivors' places in the next queue are known before
 // the shading kernel writes them.
+#ifndef PT_TRACE_OCC
+#define PT_TRACE_OCC 5
+#endif
+// Outside LDS in 256-thread workgroups the walk waits on memory and a fifth wave per SIMD is worth more than
+// the registers beyond 96 (measured: the same kernel at 4 waves per SIMD walks a quarter fewer rays per second).
 template <int MODE, int BLOCK, bool COUNT, bool RES, bool REFILL>
-__global__ __launch_bounds__(BLOCK) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, PathFrame F, int depth,
+__global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256 && mode_wide(MODE) && !COUNT) ? PT_TRACE_OCC : 1) void k_trace_queue(SceneDev S, LdsPlan plan, uint32_t kRun, PathFrame F, int depth,
                                                        uint32_t n, QueueDev q, HitDev hit, uint8_t *alive_out,
                                                        uint32_t *head, unsigned long long *stats) {
   uint32_t stk;
