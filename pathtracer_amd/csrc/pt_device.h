@@ -147,10 +147,6 @@ struct HitRec {
 // the smallest t a triangle hit can have (1e-6, object.cpp:425), so that no box is left before a hit inside
 // it can count.  See SceneDev::tmin_own.
 #define PT_OWN_BOX_TMIN 5.0e-7f
-// 1: launches over the fast tree of a scene outside LDS issue all loads of a round together (walk_round_mem).
-#ifndef PT_OVERLAP_LOADS
-#define PT_OVERLAP_LOADS 1
-#endif
 
 // Which tree a traversal mode walks, and whether it prunes.
 __host__ __device__ constexpr bool mode_prunes(int mode) { return mode != PT_TRACE_EXACT; }
@@ -308,20 +304,19 @@ struct RayState {
   int sp;
   bool live;          // cur is valid
   bool found;         // ANY: a triangle was hit
-  // Fast tree outside LDS (walk_round_mem): a closest-hit walk first runs without looking at gates (the best hit
-  // of all candidates, `gate` remembering the winner's gate box), then `verify` is set and the next round tests
-  // that one gate; if the ray fails it (rare: the gate encloses the triangle) the walk starts over with every
-  // candidate's gate tested as it is found (`gated`).
-  bool gated, verify;
-  uint32_t gate;
   // fast tree only: where this ray finds its near and far planes of a node (pieces 2*axis + sign and
   // 2*axis + 1 - sign): offsets in float4 into the LDS copy (piece * staged nodes) and into a global node
   uint32_t ln[3], lf[3], gn[3], gf[3];
+  // fast tree of a scene outside LDS: the same as three sign bits (bit a: 1/d negative on axis a) and three
+  // zero bits (bit 3 + a: d == 0 on axis a); the piece offsets and the two plane origins are formed from them
+  // at every node.  Such a walk waits on memory, not on the vector unit, and the sixteen registers this saves
+  // per lane are a sixth wave per SIMD.
+  uint32_t sgn;
   HitRec best;
-  __device__ __forceinline__ bool done() const { return !live && pend == 0 && !verify; }
+  __device__ __forceinline__ bool done() const { return !live && pend == 0; }
 };
 
-template <int MODE, bool WANT_N>
+template <int MODE, bool WANT_N, bool RES = true>
 __device__ __forceinline__ void walk_init(const SceneDev &S, const LdsScene &C, RayState &st, V3 o, V3 d) {
   // 1/d per axis as AABB::intersect forms it (object.cpp:183).  An axis with d == 0 is
   // skipped there without checking that the origin lies inside the slab; a NaN reciprocal
@@ -338,15 +333,22 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, const LdsScene &C, 
   st.ix = d.x != 0.0f ? 1.0f / d.x : skip;
   st.iy = d.y != 0.0f ? 1.0f / d.y : skip;
   st.iz = d.z != 0.0f ? 1.0f / d.z : skip;
-  const float mx = (mode_prunes(MODE) && d.x == 0.0f) ? S.margin : 0.0f;
-  const float my = (mode_prunes(MODE) && d.y == 0.0f) ? S.margin : 0.0f;
-  const float mz = (mode_prunes(MODE) && d.z == 0.0f) ? S.margin : 0.0f;
-  st.on = mk(o.x + mx, o.y + my, o.z + mz);
-  st.of = mk(o.x - mx, o.y - my, o.z - mz);
-  st.sx = st.ix < 0.0f;
-  st.sy = st.iy < 0.0f;
-  st.sz = st.iz < 0.0f;
-  if (mode_wide(MODE)) {
+  constexpr bool LEAN = mode_wide(MODE) && !RES;
+  st.sgn = 0u;
+  if constexpr (LEAN) {
+    st.sgn = (st.ix < 0.0f ? 1u : 0u) | (st.iy < 0.0f ? 2u : 0u) | (st.iz < 0.0f ? 4u : 0u) |
+             (d.x == 0.0f ? 8u : 0u) | (d.y == 0.0f ? 16u : 0u) | (d.z == 0.0f ? 32u : 0u);
+  } else {
+    const float mx = (mode_prunes(MODE) && d.x == 0.0f) ? S.margin : 0.0f;
+    const float my = (mode_prunes(MODE) && d.y == 0.0f) ? S.margin : 0.0f;
+    const float mz = (mode_prunes(MODE) && d.z == 0.0f) ? S.margin : 0.0f;
+    st.on = mk(o.x + mx, o.y + my, o.z + mz);
+    st.of = mk(o.x - mx, o.y - my, o.z - mz);
+    st.sx = st.ix < 0.0f;
+    st.sy = st.iy < 0.0f;
+    st.sz = st.iz < 0.0f;
+  }
+  if (mode_wide(MODE) && !LEAN) {
     const uint32_t s3[3] = {st.sx ? 1u : 0u, st.sy ? 1u : 0u, st.sz ? 1u : 0u};
     st.sx = st.sy = st.sz = false;  // the fast tree's walk addresses its planes by sign (below) and keeps no sign flags
 #pragma unroll
@@ -372,9 +374,6 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, const LdsScene &C, 
   st.sp = 0;
   st.live = true;
   st.found = false;
-  st.gated = false;
-  st.verify = false;
-  st.gate = ptl::NO_GATE;
 }
 
 // The reference's box test (AABB::intersect, object.cpp:179-195) for the gate of a triangle record of the
@@ -472,23 +471,38 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
       const uint32_t node = st.cur & ~ptl::REF_NOCULL;
       // four children; this ray's near planes of all four come as one float4 per axis, its far planes too
       float4 nx, fx, ny, fy, nz, fz, rr;
-      if (RES || node < C.n_nodes) {
+      pt_f2 onx, ony, onz, ofx, ofy, ofz;
+      if constexpr (RES) {
         const uint32_t at = C.node_base + node;
         nx = lds_f4(at + st.ln[0]); fx = lds_f4(at + st.lf[0]);
         ny = lds_f4(at + st.ln[1]); fy = lds_f4(at + st.lf[1]);
         nz = lds_f4(at + st.ln[2]); fz = lds_f4(at + st.lf[2]);
         rr = lds_f4(at + 6u * C.n_nodes);
+        onx = splat2(st.on.x); ony = splat2(st.on.y); onz = splat2(st.on.z);
+        ofx = splat2(st.of.x); ofy = splat2(st.of.y); ofz = splat2(st.of.z);
       } else {
-        const size_t at = 8u * (size_t)node;
-        nx = glb_f4(S.nodes4, at + st.gn[0]); fx = glb_f4(S.nodes4, at + st.gf[0]);
-        ny = glb_f4(S.nodes4, at + st.gn[1]); fy = glb_f4(S.nodes4, at + st.gf[1]);
-        nz = glb_f4(S.nodes4, at + st.gn[2]); fz = glb_f4(S.nodes4, at + st.gf[2]);
-        rr = glb_f4(S.nodes4, at + 6);
+        // piece 2*axis + sign holds this ray's near planes, 2*axis + 1 - sign its far planes
+        const uint32_t px = st.sgn & 1u, py = 2u + ((st.sgn >> 1) & 1u), pz = 4u + ((st.sgn >> 2) & 1u);
+        if (node < C.n_nodes) {
+          const uint32_t at = C.node_base + node, n = C.n_nodes;
+          nx = lds_f4(at + px * n); fx = lds_f4(at + (px ^ 1u) * n);
+          ny = lds_f4(at + py * n); fy = lds_f4(at + (py ^ 1u) * n);
+          nz = lds_f4(at + pz * n); fz = lds_f4(at + (pz ^ 1u) * n);
+          rr = lds_f4(at + 6u * n);
+        } else {
+          const size_t at = 8u * (size_t)node;
+          nx = glb_f4(S.nodes4, at + px); fx = glb_f4(S.nodes4, at + (px ^ 1u));
+          ny = glb_f4(S.nodes4, at + py); fy = glb_f4(S.nodes4, at + (py ^ 1u));
+          nz = glb_f4(S.nodes4, at + pz); fz = glb_f4(S.nodes4, at + (pz ^ 1u));
+          rr = glb_f4(S.nodes4, at + 6);
+        }
+        // the slab of an axis with d == 0 is taken S.margin wider (see walk_init): the same sums as st.on / st.of
+        const float mx = (st.sgn & 8u) ? S.margin : 0.0f, my = (st.sgn & 16u) ? S.margin : 0.0f, mz = (st.sgn & 32u) ? S.margin : 0.0f;
+        onx = splat2(st.o.x + mx); ony = splat2(st.o.y + my); onz = splat2(st.o.z + mz);
+        ofx = splat2(st.o.x - mx); ofy = splat2(st.o.y - my); ofz = splat2(st.o.z - mz);
       }
       if (COUNT) n_boxes += 4;
       const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
-      const pt_f2 onx = splat2(st.on.x), ony = splat2(st.on.y), onz = splat2(st.on.z);
-      const pt_f2 ofx = splat2(st.of.x), ofy = splat2(st.of.y), ofz = splat2(st.of.z);
       const pt_f2 ix = splat2(st.ix), iy = splat2(st.iy), iz = splat2(st.iz);
       const pt_f2 ax01 = (pair2(nx.x, nx.y) - onx) * ix, ax23 = (pair2(nx.z, nx.w) - onx) * ix;
       const pt_f2 ay01 = (pair2(ny.x, ny.y) - ony) * iy, ay23 = (pair2(ny.z, ny.w) - ony) * iy;
@@ -651,175 +665,11 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   }
 }
 
-// The same round for the fast tree of a scene outside LDS, where every fetch costs a trip to L2 or beyond and
-// a round's cost is the number of such trips it makes one after the other.  walk_round makes up to three: the
-// node, then (when the wave tests its parked leaves) the triangles, then the gate of a hit that wins.  Here
-// the round decides first, from the state the previous round left, which lanes test their parked leaf, issues
-// every load of the round at once (node pieces, triangle records, the gate of a finished walk) and computes
-// afterwards: one trip per round.  A closest-hit walk does not look at gates while it runs: it keeps the best
-// hit of all candidates and tests the winner's gate alone at the end (RayState::verify), which gives the same
-// answer whenever that test passes: the winner is then the best of the candidates that pass their gates too,
-// and nothing was pruned that could have beaten it.  When it fails, the walk is run again for that ray with the
-// gates tested hit by hit.  A leaf found in this round is parked and tested in a later one, which changes the
-// order of the tests but not their outcome (ties go by rank).
-template <int MODE, bool ANY, bool COUNT, bool WANT_N>
-__device__ __forceinline__ void walk_round_mem(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
-                                               uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
-  static_assert(mode_wide(MODE), "the fast tree only");
-  const bool ver_lane = !ANY && st.verify;
-  if (ver_lane) {
-    // the winner's gate, with the reference's arithmetic (gate_pass)
-    const float4 g0 = glb_f4(S.gates, 2u * (size_t)st.gate);
-    const float4 g1 = glb_f4(S.gates, 2u * (size_t)st.gate + 1);
-    if (COUNT) n_boxes += 1;
-    const float nan = __builtin_nanf("");
-    const float ix = st.d.x != 0.0f ? st.ix : nan, iy = st.d.y != 0.0f ? st.iy : nan, iz = st.d.z != 0.0f ? st.iz : nan;
-    const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
-    const float ax = ((sx ? g1.x : g0.x) - st.o.x) * ix, bx = ((sx ? g0.x : g1.x) - st.o.x) * ix;
-    const float ay = ((sy ? g1.y : g0.y) - st.o.y) * iy, by = ((sy ? g0.y : g1.y) - st.o.y) * iy;
-    const float az = ((sz ? g1.z : g0.z) - st.o.z) * iz, bz = ((sz ? g0.z : g1.z) - st.o.z) * iz;
-    const float tn = fmaxf(fmaxf(fmaxf(1e-5f, ax), ay), az);
-    const float tf = fminf(fminf(fminf(__builtin_inff(), bx), by), bz);
-    st.verify = false;
-    st.gate = ptl::NO_GATE;  // looked at
-    if (!(tf >= tn)) {
-      // the ray does not reach that triangle's leaf in the reference: again, with every candidate's gate tested
-      const V3 o = st.o, d = st.d;
-      walk_init<MODE, WANT_N>(S, C, st, o, d);
-      st.gated = true;
-    }
-  }
-  const bool node_lane = st.live && !(st.cur & ptl::REF_LEAF);
-  // ---- every load of the round
-  float4 nx, fx, ny, fy, nz, fz, rr;
-  float4 a0, b0, c0, a1, b1, c1;
-  uint32_t node = 0, first = 0;
-  bool two = false;
-  if (node_lane) {
-    node = st.cur & ~ptl::REF_NOCULL;
-    if (node < C.n_nodes) {
-      const uint32_t at = C.node_base + node;
-      nx = lds_f4(at + st.ln[0]); fx = lds_f4(at + st.lf[0]);
-      ny = lds_f4(at + st.ln[1]); fy = lds_f4(at + st.lf[1]);
-      nz = lds_f4(at + st.ln[2]); fz = lds_f4(at + st.lf[2]);
-      rr = lds_f4(at + 6u * C.n_nodes);
-    } else {
-      const size_t at = 8u * (size_t)node;
-      nx = glb_f4(S.nodes4, at + st.gn[0]); fx = glb_f4(S.nodes4, at + st.gf[0]);
-      ny = glb_f4(S.nodes4, at + st.gn[1]); fy = glb_f4(S.nodes4, at + st.gf[1]);
-      nz = glb_f4(S.nodes4, at + st.gn[2]); fz = glb_f4(S.nodes4, at + st.gf[2]);
-      rr = glb_f4(S.nodes4, at + 6);
-    }
-  }
-  // ---- the node step
-  if (node_lane) {
-    float far = (!ANY) ? st.cull : __builtin_inff();
-    if (!ANY && S.n_ill != 0u && (st.cur & ptl::REF_NOCULL)) far = __builtin_inff();
-    if (COUNT) n_boxes += 4;
-    const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
-    const pt_f2 onx = splat2(st.on.x), ony = splat2(st.on.y), onz = splat2(st.on.z);
-    const pt_f2 ofx = splat2(st.of.x), ofy = splat2(st.of.y), ofz = splat2(st.of.z);
-    const pt_f2 ix = splat2(st.ix), iy = splat2(st.iy), iz = splat2(st.iz);
-    const pt_f2 ax01 = (pair2(nx.x, nx.y) - onx) * ix, ax23 = (pair2(nx.z, nx.w) - onx) * ix;
-    const pt_f2 ay01 = (pair2(ny.x, ny.y) - ony) * iy, ay23 = (pair2(ny.z, ny.w) - ony) * iy;
-    const pt_f2 az01 = (pair2(nz.x, nz.y) - onz) * iz, az23 = (pair2(nz.z, nz.w) - onz) * iz;
-    const pt_f2 bx01 = (pair2(fx.x, fx.y) - ofx) * ix, bx23 = (pair2(fx.z, fx.w) - ofx) * ix;
-    const pt_f2 by01 = (pair2(fy.x, fy.y) - ofy) * iy, by23 = (pair2(fy.z, fy.w) - ofy) * iy;
-    const pt_f2 bz01 = (pair2(fz.x, fz.y) - ofz) * iz, bz23 = (pair2(fz.z, fz.w) - ofz) * iz;
-    const float tn0 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.x), ay01.x), az01.x), tf0 = fminf(fminf(fminf(far, bx01.x), by01.x), bz01.x);
-    const float tn1 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.y), ay01.y), az01.y), tf1 = fminf(fminf(fminf(far, bx01.y), by01.y), bz01.y);
-    const float tn2 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.x), ay23.x), az23.x), tf2 = fminf(fminf(fminf(far, bx23.x), by23.x), bz23.x);
-    const float tn3 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.y), ay23.y), az23.y), tf3 = fminf(fminf(fminf(far, bx23.y), by23.y), bz23.y);
-    const bool h0 = tf0 >= tn0, h1 = tf1 >= tn1, h2 = tf2 >= tn2, h3 = tf3 >= tn3;
-    if (h0 || h1 || h2 || h3) {
-      const float inf = __builtin_inff();
-      const float k0 = h0 ? tn0 : inf, k1 = h1 ? tn1 : inf, k2 = h2 ? tn2 : inf, k3 = h3 ? tn3 : inf;
-      const float km = fminf(fminf(k0, k1), fminf(k2, k3));
-      const bool c0_ = h0 && k0 == km;
-      const bool c1_ = !c0_ && h1 && k1 == km;
-      const bool c2_ = !c0_ && !c1_ && h2 && k2 == km;
-      const bool c3_ = !c0_ && !c1_ && !c2_;
-      if (h3 && !c3_) { push_ref(C, stk, stride, st.sp, r3); ++st.sp; }
-      if (h2 && !c2_) { push_ref(C, stk, stride, st.sp, r2); ++st.sp; }
-      if (h1 && !c1_) { push_ref(C, stk, stride, st.sp, r1); ++st.sp; }
-      if (h0 && !c0_) { push_ref(C, stk, stride, st.sp, r0); ++st.sp; }
-      st.cur = c0_ ? r0 : (c1_ ? r1 : (c2_ ? r2 : r3));
-    } else if (st.sp == 0) {
-      st.live = false;
-    } else {
-      --st.sp;
-      st.cur = pop_ref(C, stk, stride, st.sp);
-    }
-  }
-  // ---- a lane that has arrived at a leaf parks it and goes on with its next node
-  if (st.live && (st.cur & ptl::REF_LEAF) && st.pend == 0) {
-    st.pend = st.cur;
-    if (st.sp == 0) {
-      st.live = false;
-    } else {
-      --st.sp;
-      st.cur = pop_ref(C, stk, stride, st.sp);
-    }
-  }
-  // ---- the parked leaves, when enough lanes hold one (or no lane has node work left)
-  const unsigned long long m_pend = __ballot(st.pend != 0);
-  const unsigned long long m_node = __ballot(st.live && !(st.cur & ptl::REF_LEAF));
-  bool enough;
-  if (ANY) enough = (uint32_t)__popcll(m_pend) * 64u >= S.quorum_any * (uint32_t)__popcll(__ballot(!st.done()));
-  else enough = (uint32_t)__popcll(m_pend) >= quorum;
-  const bool tri_lane = st.pend != 0 && (enough || m_node == 0);
-  if (tri_lane) {
-    first = st.pend & ptl::REF_FIRST_MASK;
-    two = ((st.pend >> 28) & 1u) != 0u;  // the fast tree's leaves hold one or two triangles
-    {
-      const uint32_t s1 = two ? first + 1u : first;
-      const size_t at0 = 3u * (size_t)first, at1 = 3u * (size_t)s1;
-      a0 = glb_f4(S.tris4, at0); b0 = glb_f4(S.tris4, at0 + 1); c0 = glb_f4(S.tris4, at0 + 2);
-      a1 = glb_f4(S.tris4, at1); b1 = glb_f4(S.tris4, at1 + 1); c1 = glb_f4(S.tris4, at1 + 2);
-    }
-    st.pend = 0;
-    if (COUNT) n_tris += two ? 2u : 1u;
-    bool h0, h1;
-    pt_f2 t2, u2, v2;
-    tri_test2(a0, b0, c0, a1, b1, c1, st.o, st.d, h0, h1, t2, u2, v2);
-    h1 = h1 && two;
-    const uint32_t s1 = two ? first + 1u : first;
-    if (ANY) {
-      // a hit counts only where the reference reaches that triangle's leaf
-      if (h0) { h0 = gate_pass<false>(S, C, st, __float_as_uint(c0.y)); if (COUNT) n_boxes += 1; }
-      if (h1 && !h0) { h1 = gate_pass<false>(S, C, st, __float_as_uint(c1.y)); if (COUNT) n_boxes += 1; }
-      if (h0 || h1) {
-        st.found = true;
-        st.live = false;
-      }
-    } else {
-      if (st.gated) {
-        consider_hit<MODE, COUNT, WANT_N, false>(S, C, st, n_boxes, h0, t2.x, first, c0);
-        consider_hit<MODE, COUNT, WANT_N, false>(S, C, st, n_boxes, h1, t2.y, s1, c1);
-      } else {
-        const uint32_t k0 = __float_as_uint(c0.w), k1 = __float_as_uint(c1.w);
-        if (h0 && (t2.x < st.best.t || (t2.x == st.best.t && (int32_t)k0 > (int32_t)st.best.rank))) {
-          st.best.t = t2.x; st.best.slot = first; st.best.rank = k0; st.gate = __float_as_uint(c0.y);
-        }
-        if (h1 && (t2.y < st.best.t || (t2.y == st.best.t && (int32_t)k1 > (int32_t)st.best.rank))) {
-          st.best.t = t2.y; st.best.slot = s1; st.best.rank = k1; st.gate = __float_as_uint(c1.y);
-        }
-      }
-      st.cull = st.best.t + (st.best.t * PT_SLACK_REL + PT_SLACK_ABS);
-    }
-  }
-  // ---- a closest-hit walk that has run out of work has its winner's gate looked at in the next round
-  if (!ANY && !st.live && st.pend == 0 && !st.verify && !st.gated && st.gate != ptl::NO_GATE) {
-    st.verify = true;
-  }
-}
-
-// One round of whichever form fits the launch.
+// One round.
 template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES>
 __device__ __forceinline__ void walk_step(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
                                           uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
-  if constexpr (mode_wide(MODE) && !RES && !ANY && PT_OVERLAP_LOADS) walk_round_mem<MODE, ANY, COUNT, WANT_N>(S, C, st, stk, stride, n_boxes, n_tris, quorum);
-  else walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, quorum);
+  walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, quorum);
 }
 
 // The whole walk for one ray per lane; all lanes return together.
@@ -827,7 +677,7 @@ template <int MODE, bool ANY, bool COUNT, bool WANT_N = false, bool RES = false>
 __device__ __forceinline__ bool walk(const SceneDev &S, const LdsScene &C, V3 o, V3 d, uint32_t stk, uint32_t stride,
                                      HitRec &best, uint32_t &n_boxes, uint32_t &n_tris) {
   RayState st;
-  walk_init<MODE, WANT_N>(S, C, st, o, d);
+  walk_init<MODE, WANT_N, RES>(S, C, st, o, d);
   do {
     walk_step<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, S.quorum);
   } while (__ballot(!st.done()) != 0);

@@ -254,7 +254,18 @@ static int make_plan(PtScene *s, bool wide) {
     // five waves per SIMD at that size.  A sixth of the CU's LDS each: with a fifth (32 KiB) the fifth
     // workgroup was measured not to become resident.
     p.block = 256;
-    p.resident = layout(lds_cu / 6);
+    // workgroups per CU the LDS is cut for (four waves each)
+    // Measured with 69-72 registers per lane (up to seven waves per SIMD): 260 k triangles 6.43 / 6.54 / 6.12 G
+    // rays/s at 5 / 6 / 7 workgroups, 1 M triangles with 64 lights 5.67 / 6.10 / 6.02, 7 M triangles 3.51 / 3.26 /
+    // 3.16: more rays in flight help until their working set outgrows the caches, which the 7 M triangles
+    // (over 600 MB of nodes and triangles against 256 MB of Infinity Cache) do at once.
+    const size_t tree_bytes = node_bytes + tri_bytes;
+    size_t share = tree_bytes > (200u << 20) ? 5 : 6;
+    if (const char *e = std::getenv("PT_LDS_SHARE")) {  // tuning knob
+      const int v = std::atoi(e);
+      if (v >= 4 && v <= 8) share = (size_t)v;
+    }
+    p.resident = layout(lds_cu / share - 1024);  // a little under the share, so that exactly `share` workgroups become resident
   }
   p.lds.stack_lds = (uint32_t)p.stack;
   p.lds.spill = nullptr;

@@ -310,7 +310,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
         V3 o, d;
         if (i < n && fetch(i, o, d)) {
           RayState st;
-          walk_init<MODE, WANT_N>(S, C, st, o, d);
+          walk_init<MODE, WANT_N, RES>(S, C, st, o, d);
           do {
             walk_step<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, BLOCK, nb, nt, S.quorum);
           } while (__ballot(!st.done()) != 0);
@@ -330,9 +330,6 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
     RayState st;
     st.live = false;
     st.pend = 0;
-    st.verify = false;
-    st.gated = false;
-    st.gate = ptl::NO_GATE;
     for (;;) {
       const unsigned long long m_busy = __ballot(busy);
       const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
@@ -360,7 +357,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
           const uint64_t i = pool + rank;
           V3 o, d;
           if (i < pool_end && fetch(i, o, d)) {
-            walk_init<MODE, WANT_N>(S, C, st, o, d);
+            walk_init<MODE, WANT_N, RES>(S, C, st, o, d);
             mine = i;
             busy = true;
           }
