@@ -118,7 +118,7 @@ typedef struct PtSceneInfo {
   uint32_t device;         /* HIP device ordinal the scene lives on */
   uint64_t device_bytes;   /* bytes of HBM held by the scene */
   uint32_t boxes_nested;   /* 1: every internal box encloses what is below it (see PtNode); 0: PT_TRACE_FAST runs as PT_TRACE_EXACT */
-  uint32_t reserved;
+  uint32_t n_oct_nodes;    /* 128-byte eight-child nodes of the fast tree's form for scenes outside on-chip memory (0: not built) */
 } PtSceneInfo;
 
 /* Camera state read by Camera::render (camera.cpp:49-58,161-169).  `euler` is

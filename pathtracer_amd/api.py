@@ -42,7 +42,7 @@ class PtSceneInfo(C.Structure):
     _fields_ = [("n_meshes", C.c_uint32), ("n_tris", C.c_uint32), ("n_lights", C.c_uint32),
                 ("n_wide_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("n_fast_nodes", C.c_uint32),
                 ("fast_max_depth", C.c_uint32), ("n_gates", C.c_uint32), ("device", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("boxes_nested", C.c_uint32), ("reserved", C.c_uint32)]
+                ("device_bytes", C.c_uint64), ("boxes_nested", C.c_uint32), ("n_oct_nodes", C.c_uint32)]
 
 
 class PtCamera(C.Structure):

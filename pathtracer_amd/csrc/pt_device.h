@@ -115,11 +115,12 @@ struct SceneDev {
   // the fast mode's own tree (pt_fasttree.cpp): four-child nodes, triangle records in its leaf order,
   // the global triangle id and texture coordinates per such record, the gate boxes
   const ptl::Quad4Node *nodes4;
+  const ptl::Oct8Node *nodes8;    // the same tree with eight children per node (scenes outside LDS), or null
   const ptl::TriRec4 *tris4;
   const uint32_t *tri_id4;
   const ptl::GateBox *gates;
   const float *tri_uv4;
-  uint32_t n_nodes4, n_tris4, n_gates;
+  uint32_t n_nodes4, n_tris4, n_gates, n_nodes8;
   uint32_t n_ill;                 // ill-conditioned triangles in the scene (REF_NOCULL references exist iff > 0)
   float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
   uint32_t quorum;      // lanes of a wave that must hold a parked leaf before triangles are tested (closest hit)
@@ -148,9 +149,13 @@ struct HitRec {
 // it can count.  See SceneDev::tmin_own.
 #define PT_OWN_BOX_TMIN 5.0e-7f
 
+// The fast mode over the eight-child form of its tree: what PT_TRACE_FAST runs as on a scene that does not fit
+// LDS (chosen by the library, not by callers).
+#define PT_TRACE_FAST_OCT 3
 // Which tree a traversal mode walks, and whether it prunes.
 __host__ __device__ constexpr bool mode_prunes(int mode) { return mode != PT_TRACE_EXACT; }
-__host__ __device__ constexpr bool mode_wide(int mode) { return mode == PT_TRACE_FAST; }
+__host__ __device__ constexpr bool mode_wide(int mode) { return mode == PT_TRACE_FAST || mode == PT_TRACE_FAST_OCT; }
+__host__ __device__ constexpr bool mode_oct(int mode) { return mode == PT_TRACE_FAST_OCT; }
 
 // Möller–Trumbore exactly as Triangle::intersect evaluates it (object.cpp:406-429).
 // Returns true when the reference would return a hit.
@@ -327,7 +332,9 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, const LdsScene &C, 
   // The box is taken S.margin wider for this check (separate origins for the two planes of
   // the slab): node boxes touch triangle edges, and an edge a rounding error away from the
   // ray's plane can still be hit by the reference's triangle test.
-  const float skip = mode_prunes(MODE) ? __builtin_inff() : __builtin_nanf("");
+  // The eight-child tree forms its distances as index * (step / d) + (base - o) / d, where an infinite 1/d would
+  // turn the sum into NaN; it uses 2^60 instead: the same decision (the sign of plane - o decides), finite sums.
+  const float skip = mode_oct(MODE) ? 0x1p60f : (mode_prunes(MODE) ? __builtin_inff() : __builtin_nanf(""));
   st.o = o;
   st.d = d;
   st.ix = d.x != 0.0f ? 1.0f / d.x : skip;
@@ -463,7 +470,77 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   constexpr bool PRUNE = mode_prunes(MODE), WIDE = mode_wide(MODE);
   if (st.live && !(st.cur & ptl::REF_LEAF)) {
     float far = (PRUNE && !ANY) ? st.cull : __builtin_inff();
-    if constexpr (WIDE) {
+    if constexpr (mode_oct(MODE)) {
+      // Eight children on a grid: a child's plane is base + index * step, so its distance along the ray is
+      // index * (step / d) + (base - o) / d: one fused multiply-add per plane after six products per node.
+      const uint32_t node = st.cur;
+      float4 p0, qx, qy, qz, ra, rb;
+      if (node < C.n_nodes) {
+        const uint32_t at = C.node_base + node, n = C.n_nodes;
+        p0 = lds_f4(at); qx = lds_f4(at + n); qy = lds_f4(at + 2u * n); qz = lds_f4(at + 3u * n);
+        ra = lds_f4(at + 4u * n); rb = lds_f4(at + 5u * n);
+      } else {
+        const size_t at = 8u * (size_t)node;
+        p0 = glb_f4(S.nodes8, at); qx = glb_f4(S.nodes8, at + 1); qy = glb_f4(S.nodes8, at + 2); qz = glb_f4(S.nodes8, at + 3);
+        ra = glb_f4(S.nodes8, at + 4); rb = glb_f4(S.nodes8, at + 5);
+      }
+      if (COUNT) n_boxes += 8;
+      const uint32_t ex = __float_as_uint(p0.w);
+      const float ax = __uint_as_float((ex & 0xffu) << 23) * st.ix;
+      const float ay = __uint_as_float((ex & 0xff00u) << 15) * st.iy;
+      const float az = __uint_as_float((ex & 0xff0000u) << 7) * st.iz;
+      const float mx = (st.sgn & 8u) ? S.margin : 0.0f, my = (st.sgn & 16u) ? S.margin : 0.0f, mz = (st.sgn & 32u) ? S.margin : 0.0f;
+      const float bnx = (p0.x - (st.o.x + mx)) * st.ix, bfx = (p0.x - (st.o.x - mx)) * st.ix;
+      const float bny = (p0.y - (st.o.y + my)) * st.iy, bfy = (p0.y - (st.o.y - my)) * st.iy;
+      const float bnz = (p0.z - (st.o.z + mz)) * st.iz, bfz = (p0.z - (st.o.z - mz)) * st.iz;
+      // index bytes of this ray's near and far planes: words 0-1 hold lo, words 2-3 hi
+      const bool gx = (st.sgn & 1u) != 0u, gy = (st.sgn & 2u) != 0u, gz = (st.sgn & 4u) != 0u;
+      const uint32_t x0 = __float_as_uint(qx.x), x1 = __float_as_uint(qx.y), x2 = __float_as_uint(qx.z), x3 = __float_as_uint(qx.w);
+      const uint32_t y0 = __float_as_uint(qy.x), y1 = __float_as_uint(qy.y), y2 = __float_as_uint(qy.z), y3 = __float_as_uint(qy.w);
+      const uint32_t z0 = __float_as_uint(qz.x), z1 = __float_as_uint(qz.y), z2 = __float_as_uint(qz.z), z3 = __float_as_uint(qz.w);
+      const uint32_t nxw[2] = {gx ? x2 : x0, gx ? x3 : x1}, fxw[2] = {gx ? x0 : x2, gx ? x1 : x3};
+      const uint32_t nyw[2] = {gy ? y2 : y0, gy ? y3 : y1}, fyw[2] = {gy ? y0 : y2, gy ? y1 : y3};
+      const uint32_t nzw[2] = {gz ? z2 : z0, gz ? z3 : z1}, fzw[2] = {gz ? z0 : z2, gz ? z1 : z3};
+      const uint32_t r[8] = {__float_as_uint(ra.x), __float_as_uint(ra.y), __float_as_uint(ra.z), __float_as_uint(ra.w),
+                             __float_as_uint(rb.x), __float_as_uint(rb.y), __float_as_uint(rb.z), __float_as_uint(rb.w)};
+      float tn[8];
+      uint32_t hm = 0u;
+      float km = __builtin_inff();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int w = k >> 2, sh = 8 * (k & 3);
+        const float t0x = __builtin_fmaf((float)((nxw[w] >> sh) & 0xffu), ax, bnx), t1x = __builtin_fmaf((float)((fxw[w] >> sh) & 0xffu), ax, bfx);
+        const float t0y = __builtin_fmaf((float)((nyw[w] >> sh) & 0xffu), ay, bny), t1y = __builtin_fmaf((float)((fyw[w] >> sh) & 0xffu), ay, bfy);
+        const float t0z = __builtin_fmaf((float)((nzw[w] >> sh) & 0xffu), az, bnz), t1z = __builtin_fmaf((float)((fzw[w] >> sh) & 0xffu), az, bfz);
+        // NaN (an infinite 1/d against a plane it cannot order) never restricts
+        const float n_ = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x), t0y), t0z);
+        const float f_ = fminf(fminf(fminf(far, t1x), t1y), t1z);
+        const bool h = f_ >= n_;
+        tn[k] = h ? n_ : __builtin_inff();
+        hm |= h ? (1u << k) : 0u;
+        km = fminf(km, tn[k]);
+      }
+      if (hm != 0u) {
+        // nearest child next; the others wait on the stack, slot 0 on top
+        uint32_t em = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) em |= (tn[k] == km && ((hm >> k) & 1u)) ? (1u << k) : 0u;
+        const uint32_t c = (uint32_t)__builtin_ctz(em);
+        const uint32_t rest = hm & ~(1u << c);
+#pragma unroll
+        for (int k = 7; k >= 0; --k)
+          if ((rest >> k) & 1u) { push_ref(C, stk, stride, st.sp, r[k]); ++st.sp; }
+        uint32_t nc = r[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) nc = c == (uint32_t)k ? r[k] : nc;
+        st.cur = nc;
+      } else if (st.sp == 0) {
+        st.live = false;
+      } else {
+        --st.sp;
+        st.cur = pop_ref(C, stk, stride, st.sp);
+      }
+    } else if constexpr (WIDE) {
       // A node reached through a REF_NOCULL reference has an ill-conditioned triangle below it, which can
       // report a hit at any distance: its children are entered whenever the ray passes their boxes, however
       // far away those begin.  (Scenes without such triangles have no such references.)

@@ -198,13 +198,15 @@ struct FastBuilder {
   // Collapses the binary tree into four-child nodes (creation order; renumbered afterwards) and lays
   // the triangle records out in leaf order.
   struct Wide {
-    uint32_t child[4];
+    uint32_t child[8];
     int n_child;
   };
   std::vector<Wide> wide;          // child = index into bn
   std::vector<uint32_t> wide_of;   // per binary node that heads a wide node: its index in `wide`
+  std::vector<Wide> wide8;         // the same collapse with up to eight children
+  std::vector<uint32_t> wide_of8;
 
-  void collapse() {
+  void collapse(int width, std::vector<Wide> &wide, std::vector<uint32_t> &wide_of) {
     wide.clear();
     wide_of.assign(bn.size(), 0xffffffffu);
     std::vector<uint32_t> todo;
@@ -216,7 +218,7 @@ struct FastBuilder {
       w.n_child = 2;
       w.child[0] = bn[b].left;
       w.child[1] = bn[b].right;
-      while (w.n_child < 4) {
+      while (w.n_child < width) {
         int pick = -1;
         float best = -1;
         for (int k = 0; k < w.n_child; ++k) {
@@ -245,10 +247,12 @@ struct FastBuilder {
   // are the reference's own, tested with the reference's arithmetic: a flat wall keeps its flat box and a ray
   // leaving that wall does not enter it); an inner node's box is the union of its children's.
   std::vector<Box3> tb;
+  std::vector<Box3> tbw;     // the same without the clipping (every plane keeps its margin)
   std::vector<uint8_t> ill;  // per binary node: an ill-conditioned triangle below it
   void test_boxes() {
     const float margin = out.margin_rel * out.max_abs_coord + 2.0e-5f;
     tb.resize(bn.size());
+    tbw.resize(bn.size());
     ill.assign(bn.size(), 0);
     out.n_ill = 0;
     for (size_t i = bn.size(); i-- > 0;) {  // children were created after their parent
@@ -256,6 +260,8 @@ struct FastBuilder {
       if (b.count == 0) {
         tb[i] = tb[b.left];
         tb[i].grow(tb[b.right]);
+        tbw[i] = tbw[b.left];
+        tbw[i].grow(tbw[b.right]);
         ill[i] = ill[b.left] | ill[b.right];
         continue;
       }
@@ -268,6 +274,7 @@ struct FastBuilder {
           ill[i] = 1;
           ++out.n_ill;
         }
+      tbw[i] = w;
       Box3 g;
       g.clear();
       bool all = true;
@@ -295,16 +302,14 @@ struct FastBuilder {
     }
   }
 
-  void emit() {
-    test_boxes();
-    // order of the wide nodes: the top of the tree breadth-first (those are the ones kept in LDS), the
-    // rest depth-first
-    const uint32_t kTop = 1280;
+  // Order of the wide nodes in memory: the top of the tree breadth-first (those are the ones kept in LDS),
+  // the rest depth-first.
+  std::vector<uint32_t> sequence(const std::vector<Wide> &wide, const std::vector<uint32_t> &wide_of, uint32_t kTop) const {
     std::vector<uint32_t> seq;
     seq.reserve(wide.size());
     std::deque<uint32_t> q;
     q.push_back(0);
-    auto kids = [&](uint32_t wi, uint32_t k[4]) {
+    auto kids = [&](uint32_t wi, uint32_t k[8]) {
       int c = 0;
       for (int j = 0; j < wide[wi].n_child; ++j)
         if (bn[wide[wi].child[j]].count == 0) k[c++] = wide_of[wide[wi].child[j]];
@@ -314,7 +319,7 @@ struct FastBuilder {
       const uint32_t wi = q.front();
       q.pop_front();
       seq.push_back(wi);
-      uint32_t k[4];
+      uint32_t k[8];
       const int c = kids(wi, k);
       for (int j = 0; j < c; ++j) q.push_back(k[j]);
     }
@@ -325,11 +330,19 @@ struct FastBuilder {
         const uint32_t wi = st.back();
         st.pop_back();
         seq.push_back(wi);
-        uint32_t k[4];
+        uint32_t k[8];
         const int c = kids(wi, k);
         for (int j = c - 1; j >= 0; --j) st.push_back(k[j]);
       }
     }
+    return seq;
+  }
+
+  std::vector<uint32_t> leaf_first;  // per binary leaf: its first record in out.tris4
+
+  void emit() {
+    test_boxes();
+    const std::vector<uint32_t> seq = sequence(wide, wide_of, 1280);
     std::vector<uint32_t> newidx(wide.size(), 0);
     for (uint32_t j = 0; j < seq.size(); ++j) newidx[seq[j]] = j;
 
@@ -348,7 +361,7 @@ struct FastBuilder {
       out.tris4.push_back(q);
       out.tri_id4.push_back(r.tri_id);
     };
-    std::vector<uint32_t> leaf_first(bn.size(), 0);
+    leaf_first.assign(bn.size(), 0);
     for (uint32_t j = 0; j < seq.size(); ++j) {
       const Wide &w = wide[seq[j]];
       for (int k = 0; k < w.n_child; ++k) {
@@ -412,6 +425,85 @@ struct FastBuilder {
     }
   }
 
+  // The eight-child form of the same binary tree (pt_layout.h, Oct8Node), over the same triangle records.
+  void emit8() {
+    out.nodes8.clear();
+    out.max_depth8 = 0;
+    if (out.n_ill != 0) return;  // boxes bounded by gates alone (or by nothing) do not go on a grid
+    for (const Box3 &b : tb)
+      for (int k = 0; k < 3; ++k)
+        if (!(b.lo[k] <= b.hi[k]) || !std::isfinite(b.lo[k]) || !std::isfinite(b.hi[k])) return;
+    const std::vector<uint32_t> seq = sequence(wide8, wide_of8, 600);
+    std::vector<uint32_t> newidx(wide8.size(), 0);
+    for (uint32_t j = 0; j < seq.size(); ++j) newidx[seq[j]] = j;
+    const uint32_t filler = (uint32_t)out.tris4.size() - 1;
+    out.nodes8.assign(seq.size(), Oct8Node());
+    for (uint32_t j = 0; j < seq.size(); ++j) {
+      const Wide &w = wide8[seq[j]];
+      Oct8Node &o = out.nodes8[j];
+      memset(&o, 0, sizeof(o));
+      uint8_t *q[3] = {o.qx, o.qy, o.qz};
+      for (int a = 0; a < 3; ++a) {
+        // exactly flat node: every child is flat on this axis at one and the same plane
+        bool flat = true;
+        const float v = tb[w.child[0]].lo[a];
+        for (int k = 0; k < w.n_child; ++k) {
+          const Box3 &c = tb[w.child[k]];
+          if (!(c.lo[a] == c.hi[a] && c.lo[a] == v)) flat = false;
+        }
+        if (flat) {
+          o.base[a] = v;
+          for (int k = 0; k < 8; ++k) { q[a][k] = k < w.n_child ? 0 : 255; q[a][8 + k] = 0; }
+          continue;  // exponent byte 0
+        }
+        // a child that is flat here keeps its margin instead (its exact plane is not on the grid)
+        double lo[8], hi[8], nlo = INFINITY, nhi = -INFINITY;
+        for (int k = 0; k < w.n_child; ++k) {
+          const Box3 &c = tb[w.child[k]], &cw = tbw[w.child[k]];
+          const bool child_flat = c.lo[a] == c.hi[a];
+          lo[k] = child_flat ? std::min(cw.lo[a], c.lo[a]) : c.lo[a];
+          hi[k] = child_flat ? std::max(cw.hi[a], c.hi[a]) : c.hi[a];
+          nlo = std::min(nlo, lo[k]);
+          nhi = std::max(nhi, hi[k]);
+        }
+        const float base = (float)nlo <= nlo ? (float)nlo : std::nextafterf((float)nlo, -INFINITY);
+        o.base[a] = base;
+        int e = -126;
+        while (e < 127 && (double)base + 254.0 * std::ldexp(1.0, e) < nhi) ++e;
+        const double step = std::ldexp(1.0, e);
+        o.exps |= (uint32_t)(e + 127) << (8 * a);
+        for (int k = 0; k < 8; ++k) {
+          if (k >= w.n_child) { q[a][k] = 255; q[a][8 + k] = 0; continue; }
+          double ql = std::floor((lo[k] - (double)base) / step), qh = std::ceil((hi[k] - (double)base) / step);
+          while (ql > 0 && (double)base + ql * step > lo[k]) ql -= 1;
+          while ((double)base + qh * step < hi[k]) qh += 1;
+          if (ql < 0) ql = 0;
+          if (qh > 255) qh = 255;  // cannot happen: 254 steps reach the node's far plane
+          q[a][k] = (uint8_t)ql;
+          q[a][8 + k] = (uint8_t)qh;
+        }
+      }
+      for (int k = 0; k < 8; ++k) {
+        if (k >= w.n_child) { o.ref[k] = REF_LEAF | filler; continue; }
+        const BinNode &c = bn[w.child[k]];
+        if (c.count > 0) o.ref[k] = REF_LEAF | ((c.count - 1) << 28) | leaf_first[w.child[k]];
+        else o.ref[k] = newidx[wide_of8[w.child[k]]];
+      }
+    }
+    uint32_t deepest = 1;
+    std::vector<std::pair<uint32_t, uint32_t>> walk;  // node, depth
+    walk.push_back(std::make_pair(0u, 1u));
+    while (!walk.empty()) {
+      const std::pair<uint32_t, uint32_t> e = walk.back();
+      walk.pop_back();
+      if (e.second > deepest) deepest = e.second;
+      const Oct8Node &o = out.nodes8[e.first];
+      for (int k = 0; k < 8; ++k)
+        if (!(o.ref[k] & REF_LEAF)) walk.push_back(std::make_pair(o.ref[k], e.second + 1));
+    }
+    out.max_depth8 = 7 * deepest + 2;  // up to seven siblings left behind per level
+  }
+
   void run() {
     n = (uint32_t)out.tris.size() - 1;  // the last record is the degenerate filler
     pb.resize(n);
@@ -448,10 +540,14 @@ struct FastBuilder {
       w.child[0] = leaf;
       wide_of[0] = 0;
       wide.push_back(w);
+      wide8 = wide;
+      wide_of8 = wide_of;
     } else {
-      collapse();
+      collapse(4, wide, wide_of);
+      collapse(8, wide8, wide_of8);
     }
     emit();
+    emit8();
   }
 };
 

@@ -614,6 +614,82 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
   return PT_OK;
 }
 
+double oct_plane(const Oct8Node &n, int axis, uint32_t index) {
+  const uint32_t e = (n.exps >> (8 * axis)) & 0xffu;
+  return e == 0 ? (double)n.base[axis] : (double)n.base[axis] + (double)index * std::ldexp(1.0, (int)e - 127);
+}
+
+// Invariants of the eight-child tree: every node reachable once, every triangle record in exactly one leaf, and
+// every box on the way down to a leaf (each decoded on its own node's grid, so a child's may reach outside its
+// parent's) around that leaf's triangles with the margin the fast tree's leaves keep: at least half of it on
+// every axis, except where a plane is exactly flat (the node's exponent byte is 0) and the triangles lie in
+// that very plane.  The test is made against the intersection of the boxes on the path.
+int check_oct_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) {
+  if (f.nodes8.empty()) return PT_OK;
+  const uint32_t n_tris = (uint32_t)f.tris4.size();
+  std::vector<uint8_t> seen(n_tris, 0), node_seen(f.nodes8.size(), 0);
+  const double leaf_margin = (double)(f.margin_rel * f.max_abs_coord + 2.0e-5f);
+  struct Item { uint32_t node; double lo[3], hi[3]; bool flat[3]; };
+  std::vector<Item> todo;
+  Item root;
+  root.node = 0;
+  for (int k = 0; k < 3; ++k) { root.lo[k] = -INFINITY; root.hi[k] = INFINITY; root.flat[k] = false; }
+  todo.push_back(root);
+  while (!todo.empty()) {
+    const Item it = todo.back();
+    todo.pop_back();
+    if (it.node >= f.nodes8.size() || node_seen[it.node]) { err = "eight-child tree: node index out of range or referenced twice"; return PT_ERR_INVALID; }
+    node_seen[it.node] = 1;
+    const Oct8Node &q = f.nodes8[it.node];
+    const uint8_t *qq[3] = {q.qx, q.qy, q.qz};
+    for (int c = 0; c < 8; ++c) {
+      double lo[3], hi[3];
+      bool unused = false, flat[3];
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = std::fmax(it.lo[k], oct_plane(q, k, qq[k][c]));
+        hi[k] = std::fmin(it.hi[k], oct_plane(q, k, qq[k][8 + c]));
+        flat[k] = it.flat[k] || ((q.exps >> (8 * k)) & 0xffu) == 0;
+        if (qq[k][c] > qq[k][8 + c]) unused = true;
+      }
+      if (unused || q.ref[c] == (REF_LEAF | (n_tris - 1))) {
+        if (q.ref[c] != (REF_LEAF | (n_tris - 1))) { err = "eight-child tree: inverted box on a used slot"; return PT_ERR_INVALID; }
+        continue;
+      }
+      if (q.ref[c] & REF_NOCULL) { err = "eight-child tree: unexpected reference flag"; return PT_ERR_INVALID; }
+      if (q.ref[c] & REF_LEAF) {
+        const uint32_t first = q.ref[c] & REF_FIRST_MASK, cnt = ((q.ref[c] >> 28) & 1u) + 1u;
+        if (first + cnt > n_tris - 1) { err = "eight-child tree: leaf range out of range"; return PT_ERR_INVALID; }
+        for (uint32_t t = first; t < first + cnt; ++t) {
+          if (seen[t]) { err = "eight-child tree: triangle in two leaves"; return PT_ERR_INVALID; }
+          seen[t] = 1;
+          const float *p = d.tri_verts + (size_t)f.tri_id4[t] * 9;
+          if (triangle_is_ill_conditioned(p)) { err = "eight-child tree: built over an ill-conditioned triangle"; return PT_ERR_INVALID; }
+          for (int k = 0; k < 3; ++k) {
+            double vmin = p[k], vmax = p[k];
+            for (int v = 1; v < 3; ++v) { vmin = std::fmin(vmin, (double)p[3 * v + k]); vmax = std::fmax(vmax, (double)p[3 * v + k]); }
+            if (flat[k]) {
+              if (!(vmin == lo[k] && vmax == hi[k])) { err = "eight-child tree: a flat plane that is not its triangles' plane"; return PT_ERR_INVALID; }
+            } else if (!(lo[k] <= vmin - 0.5 * leaf_margin) || !(hi[k] >= vmax + 0.5 * leaf_margin)) {
+              err = "eight-child tree: a leaf box plane without margin";
+              return PT_ERR_INVALID;
+            }
+          }
+        }
+      } else {
+        Item ch;
+        ch.node = q.ref[c];
+        for (int k = 0; k < 3; ++k) { ch.lo[k] = lo[k]; ch.hi[k] = hi[k]; ch.flat[k] = flat[k]; }
+        todo.push_back(ch);
+      }
+    }
+  }
+  for (uint32_t t = 0; t + 1 < n_tris; ++t)
+    if (!seen[t]) { err = "eight-child tree: triangle in no leaf"; return PT_ERR_INVALID; }
+  for (size_t i = 0; i < f.nodes8.size(); ++i)
+    if (!node_seen[i]) { err = "eight-child tree: unreachable node"; return PT_ERR_INVALID; }
+  return PT_OK;
+}
+
 int flatten_scene(const PtSceneDesc &d, FlatScene &out, std::string &err) {
   out = FlatScene();
   Flattener f(d, out, err);

@@ -27,6 +27,9 @@ struct FlatScene {
   std::vector<uint32_t> tri_id4;     // per record of tris4: global triangle id in file order (0xffffffff: the degenerate one)
   std::vector<GateBox> gates;        // boxes of the reference's internal nodes
   std::vector<float> tri_uv4;        // texture coordinates in tris4 order; empty without textures
+  std::vector<Oct8Node> nodes8;      // the same tree collapsed to eight children per node, boxes on a grid; empty when the
+                                     // scene cannot use it (an ill-conditioned triangle or a box that is not finite)
+  uint32_t max_depth8 = 0;           // stack entries the deepest descent of that one can need
   std::vector<uint32_t> tri_gate;    // per record of tris: the same gate index (input of the fast-tree builder)
   uint32_t max_depth4 = 0;           // stack entries the deepest descent of the fast tree can need
   float margin_rel = 0;              // boxes of the fast tree are widened by margin_rel * max_abs_coord + 2e-5
@@ -52,6 +55,10 @@ void build_fast_tree(const PtSceneDesc &d, FlatScene &out);
 
 // Verifies the invariants of the fast tree (used by pt_scene_check).
 int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err);
+// The same for its eight-child form (nothing to do when the scene has none).
+int check_oct_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err);
+// A child plane of an eight-child node as the kernels see it: base + index * 2^(e - 127), in double (exact).
+double oct_plane(const Oct8Node &n, int axis, uint32_t index);
 
 // Returns PT_OK or a negative PtStatus with `err` filled in.
 int flatten_scene(const PtSceneDesc &d, FlatScene &out, std::string &err);

@@ -101,16 +101,19 @@ struct PtScene {
   ptl::TexRec *d_textures = nullptr;
   uint8_t *d_texels = nullptr;
   ptl::Quad4Node *d_nodes4 = nullptr;      // the fast mode's own tree
+  ptl::Oct8Node *d_nodes8 = nullptr;       // its eight-child form (scenes outside LDS)
   ptl::TriRec4 *d_tris4 = nullptr;
   uint32_t *d_tri_id4 = nullptr;
   ptl::GateBox *d_gates = nullptr;
   float *d_tri_uv4 = nullptr;
-  uint32_t max_depth = 0, max_depth4 = 0, n_meshes = 0;
+  uint32_t max_depth = 0, max_depth4 = 0, max_depth8 = 0, n_meshes = 0;
   float max_abs_coord = 0;                 // largest finite vertex coordinate
+  bool use_oct = false;                    // PT_TRACE_FAST runs over the eight-child tree when the scene is outside LDS
   uint32_t n_unnested = 0;                 // boxes / triangles of the description that reach outside the internal box above them
   uint64_t bytes = 0;
   Plan plan;                               // launches over the reference-shaped tree (exact mode, fast-binary mode)
   Plan plan4;                              // launches over the fast tree
+  Plan plan8;                              // launches over its eight-child form
   Workspace ws;
   uint32_t *d_cnt = nullptr;               // per launch: survivors, hits, work-queue heads of trace [2], fused shade [3], visibility walk [5]
   unsigned long long *d_stats = nullptr;   // node boxes, triangle tests: closest [0,1], visibility [2,3]
@@ -188,17 +191,21 @@ static int stack_class(uint32_t depth) {
 
 // 160 KiB of LDS per CU: the per-lane stacks take STACK*4 bytes per thread, the rest
 // holds the top of the tree and, when they fit as well, all triangles.
-static int make_plan(PtScene *s, bool wide) {
-  Plan &p = wide ? s->plan4 : s->plan;
-  const uint32_t depth = wide ? s->max_depth4 : s->max_depth;
-  const uint32_t n_nodes = wide ? s->dev.n_nodes4 : s->dev.n_nodes, n_tris = wide ? s->dev.n_tris4 : s->dev.n_tris;
-  const size_t node_lds = wide ? 7 * 16 : sizeof(ptl::WideNode);  // the fast tree's nodes are kept without their padding piece
+// kind: 0 = the reference-shaped tree, 1 = the fast tree, 2 = the fast tree's eight-child form
+static int make_plan(PtScene *s, int kind) {
+  const bool wide = kind != 0, oct = kind == 2;
+  Plan &p = oct ? s->plan8 : (wide ? s->plan4 : s->plan);
+  const uint32_t depth = oct ? s->max_depth8 : (wide ? s->max_depth4 : s->max_depth);
+  const uint32_t n_nodes = oct ? s->dev.n_nodes8 : (wide ? s->dev.n_nodes4 : s->dev.n_nodes), n_tris = wide ? s->dev.n_tris4 : s->dev.n_tris;
+  // the fast tree's nodes are kept without their padding pieces
+  const size_t node_lds = oct ? 6 * 16 : (wide ? 7 * 16 : sizeof(ptl::WideNode));
   const size_t gate_bytes = wide ? (size_t)s->dev.n_gates * sizeof(ptl::GateBox) : 0;
   p.stack = stack_class(depth);
   if (!p.stack) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
   // deeper trees keep only the first entries in LDS and spill the rest to global memory, so
   // that LDS still holds 16 waves per CU and a useful part of the tree
   int cap = wide ? 16 : 24;  // a descent of the four-child tree rarely holds more than a dozen entries
+  if (oct) cap = 24;         // up to seven siblings wait per level of the eight-child tree
   if (const char *e = std::getenv("PT_STACK_CAP")) {  // tuning knob
     const int c = std::atoi(e);
     if (c >= 4 && c <= 128) cap = c;
@@ -228,7 +235,7 @@ static int make_plan(PtScene *s, bool wide) {
       if (kb < budget) budget = kb;
     }
     p.lds.n_gates = 0;
-    if (node_bytes + tri_bytes + gate_bytes <= budget) {
+    if (!oct && node_bytes + tri_bytes + gate_bytes <= budget) {
       p.lds.n_nodes = n_nodes;
       p.lds.n_tris = n_tris;
       p.lds.n_gates = wide ? s->dev.n_gates : 0;
@@ -246,7 +253,7 @@ static int make_plan(PtScene *s, bool wide) {
     p.max_blocks = per_cu * (unsigned)prop.multiProcessorCount;
     return p.lds.n_nodes == n_nodes && p.lds.n_tris == n_tris && !std::getenv("PT_NO_RESIDENT");
   };
-  p.resident = layout(lds_cu);
+  p.resident = layout(lds_cu) && !oct;  // the eight-child tree is for scenes outside LDS: it has no all-in-LDS kernels
   if (!p.resident && !block_given && p.stack <= 32) {
     // A scene outside LDS waits on memory, not on LDS: measured, the staged top of the tree buys nothing
     // there (160 KiB or 8 KiB of it: the same rate), while a fifth wave per SIMD does for the visibility
@@ -265,7 +272,7 @@ static int make_plan(PtScene *s, bool wide) {
       const int v = std::atoi(e);
       if (v >= 4 && v <= 8) share = (size_t)v;
     }
-    p.resident = layout(lds_cu / share - 1024);  // a little under the share, so that exactly `share` workgroups become resident
+    p.resident = layout(lds_cu / share - 1024) && !oct;  // a little under the share, so that exactly `share` workgroups become resident
   }
   p.lds.stack_lds = (uint32_t)p.stack;
   p.lds.spill = nullptr;
@@ -274,7 +281,7 @@ static int make_plan(PtScene *s, bool wide) {
   if (const char *e = std::getenv("PT_SPLIT")) p.split = std::atoi(e) != 0;  // tuning knob
   if (std::getenv("PT_VERBOSE"))
     std::fprintf(stderr, "ptgpu plan (%s tree): depth %u, block %d, LDS stack %d entries/lane, %u nodes + %u triangles + %u gates in LDS, %zu B LDS per workgroup, %u resident workgroups\n",
-                 wide ? "fast" : "reference-shaped", depth, p.block, p.stack, p.lds.n_nodes, p.lds.n_tris, p.lds.n_gates, p.lds_bytes, p.max_blocks);
+                 oct ? "fast, eight children" : (wide ? "fast" : "reference-shaped"), depth, p.block, p.stack, p.lds.n_nodes, p.lds.n_tris, p.lds.n_gates, p.lds_bytes, p.max_blocks);
   if (depth > (uint32_t)p.stack) {
     const size_t words = (size_t)p.max_blocks * p.block * (depth - (uint32_t)p.stack);
     HIP_TRY(hipMalloc(&p.d_spill, words * sizeof(uint32_t)));
@@ -297,11 +304,11 @@ static int make_plan(PtScene *s, bool wide) {
 static uint32_t tail_limit(const PtScene *s, int mode) {
   if (s->tail_given) return s->tail_paths;
   if (s->dev.n_lights > 4) return 0;
-  return (mode_wide(mode) ? s->plan4 : s->plan).resident ? (4u << 20) : (1u << 20);
+  return (mode_oct(mode) ? s->plan8 : (mode_wide(mode) ? s->plan4 : s->plan)).resident ? (4u << 20) : (1u << 20);
 }
 
 // Plan and device view of the scene for a traversal mode.
-static const Plan &plan_of(const PtScene *s, int mode) { return mode_wide(mode) ? s->plan4 : s->plan; }
+static const Plan &plan_of(const PtScene *s, int mode) { return mode_oct(mode) ? s->plan8 : (mode_wide(mode) ? s->plan4 : s->plan); }
 static SceneDev dev_of(const PtScene *s, int mode) {
   SceneDev d = s->dev;
   d.quorum_any = plan_of(s, mode).quorum_any;
@@ -595,6 +602,7 @@ static bool valid_mode(int mode) { return mode == PT_TRACE_EXACT || mode == PT_T
 static int effective_mode(const PtScene *s, int mode) {
   if (mode == PT_TRACE_FAST_BINARY && s->dev.n_ill != 0) return PT_TRACE_EXACT;
   if (mode == PT_TRACE_FAST && s->n_unnested != 0) return PT_TRACE_EXACT;
+  if (mode == PT_TRACE_FAST && s->use_oct && !s->plan4.resident) return PT_TRACE_FAST_OCT;
   return mode;
 }
 // Origins up to this distance from the world origin (per coordinate) are inside the range of the pruning walks.
@@ -611,6 +619,7 @@ static int with_mode(int mode, F &&f) {
     case PT_TRACE_EXACT: return f(std::integral_constant<int, PT_TRACE_EXACT>{});
     case PT_TRACE_FAST: return f(std::integral_constant<int, PT_TRACE_FAST>{});
     case PT_TRACE_FAST_BINARY: return f(std::integral_constant<int, PT_TRACE_FAST_BINARY>{});
+    case PT_TRACE_FAST_OCT: return f(std::integral_constant<int, PT_TRACE_FAST_OCT>{});
     default: return fail(PT_ERR_INVALID, "unknown trace mode");
   }
 }
@@ -708,6 +717,8 @@ void pt_scene_free(PtScene *s) {
   if (s->d_texels) (void)hipFree(s->d_texels);
   if (s->plan.d_spill) (void)hipFree(s->plan.d_spill);
   if (s->plan4.d_spill) (void)hipFree(s->plan4.d_spill);
+  if (s->plan8.d_spill) (void)hipFree(s->plan8.d_spill);
+  if (s->d_nodes8) (void)hipFree(s->d_nodes8);
   if (s->d_nodes4) (void)hipFree(s->d_nodes4);
   if (s->d_tris4) (void)hipFree(s->d_tris4);
   if (s->d_tri_id4) (void)hipFree(s->d_tri_id4);
@@ -740,6 +751,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   HIP_TRY(up(&s->d_ltris, f.light_tris));
   HIP_TRY(up(&s->d_levels, f.tri_levels));
   HIP_TRY(up(&s->d_nodes4, f.nodes4));
+  HIP_TRY(up(&s->d_nodes8, f.nodes8));
   HIP_TRY(up(&s->d_tris4, f.tris4));
   HIP_TRY(up(&s->d_tri_id4, f.tri_id4));
   HIP_TRY(up(&s->d_gates, f.gates));
@@ -769,6 +781,7 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.n_lights = (uint32_t)f.lights.size(); s->dev.n_mats = (uint32_t)f.mats.size();
   s->dev.nodes4 = s->d_nodes4; s->dev.tris4 = s->d_tris4; s->dev.tri_id4 = s->d_tri_id4; s->dev.gates = s->d_gates;
   s->dev.tri_uv4 = s->d_tri_uv4;
+  s->dev.nodes8 = s->d_nodes8; s->dev.n_nodes8 = (uint32_t)f.nodes8.size();
   s->dev.n_nodes4 = (uint32_t)f.nodes4.size(); s->dev.n_tris4 = (uint32_t)f.tris4.size(); s->dev.n_gates = (uint32_t)f.gates.size();
   s->dev.n_ill = f.n_ill;
   s->dev.margin = f.max_abs_coord * (1.0f / 2048.0f) + 2.0e-5f;
@@ -789,13 +802,16 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     const int q = std::atoi(e);
     if (q >= 1 && q <= 64) s->dev.quorum = (uint32_t)q;
   }
-  s->max_depth = f.max_depth; s->max_depth4 = f.max_depth4; s->n_meshes = f.n_meshes;
+  s->max_depth = f.max_depth; s->max_depth4 = f.max_depth4; s->max_depth8 = f.max_depth8; s->n_meshes = f.n_meshes;
+  s->use_oct = s->dev.n_nodes8 != 0;
+  if (const char *e = std::getenv("PT_NO_OCT")) s->use_oct = s->use_oct && std::atoi(e) == 0;  // tuning knob: stay on four children
   if (const char *e = std::getenv("PT_TAIL")) {  // tuning knob: 0 switches the tail kernel off
     const long v = std::atol(e);
     if (v >= 0 && v <= (1l << 30)) { s->tail_paths = (uint32_t)v; s->tail_given = true; }
   }
-  int rc = make_plan(s, false);
-  if (rc == PT_OK) rc = make_plan(s, true);
+  int rc = make_plan(s, 0);
+  if (rc == PT_OK) rc = make_plan(s, 1);
+  if (rc == PT_OK && s->dev.n_nodes8 != 0) rc = make_plan(s, 2);
   return rc;
 }
 
@@ -814,6 +830,7 @@ int pt_scene_upload(const PtSceneDesc *desc, int device, PtScene **out) {
     return fail(PT_ERR_NOMEM, "out of host memory while flattening the scene");
   }
   if (rc != PT_OK) return fail(rc, err);
+  if (!flat.nodes8.empty() && stack_class(flat.max_depth8) == 0) flat.nodes8.clear();  // too deep for its stack: the four-child form serves
   if (stack_class(flat.max_depth) == 0 || stack_class(flat.max_depth4) == 0) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
   PtScene *s = new (std::nothrow) PtScene();
   if (!s) return fail(PT_ERR_NOMEM, "out of host memory");
@@ -839,6 +856,7 @@ int pt_scene_check(const PtSceneDesc *desc, PtSceneInfo *info) {
     // a description whose boxes are not nested is never walked through the fast tree (effective_mode), whose
     // leaf boxes take those boxes at their word
     if (rc == PT_OK && flat.n_unnested == 0) rc = ptl::check_fast_tree(*desc, flat, err);
+    if (rc == PT_OK && flat.n_unnested == 0) rc = ptl::check_oct_tree(*desc, flat, err);
   } catch (const std::bad_alloc &) {
     return fail(PT_ERR_NOMEM, "out of host memory while flattening the scene");
   }
@@ -852,6 +870,7 @@ int pt_scene_check(const PtSceneDesc *desc, PtSceneInfo *info) {
     info->n_fast_nodes = (uint32_t)flat.nodes4.size(); info->fast_max_depth = flat.max_depth4;
     info->n_gates = (uint32_t)flat.gates.size();
     info->boxes_nested = flat.n_unnested == 0 ? 1u : 0u;
+    info->n_oct_nodes = (uint32_t)flat.nodes8.size();
   }
   return PT_OK;
 }
@@ -865,7 +884,7 @@ int pt_scene_info(const PtScene *s, PtSceneInfo *info) {
   info->n_fast_nodes = s->dev.n_nodes4; info->fast_max_depth = s->max_depth4; info->n_gates = s->dev.n_gates;
   info->device_bytes = s->bytes;
   info->boxes_nested = s->n_unnested == 0 ? 1u : 0u;
-  info->reserved = 0;
+  info->n_oct_nodes = s->use_oct ? s->dev.n_nodes8 : 0u;
   return PT_OK;
 }
 
@@ -884,7 +903,7 @@ static int trace_dev(PtScene *s, size_t n, const float *ox, const float *oy, con
                      hipStream_t st, bool all_near) {
   if (n == 0) return PT_OK;
   if (n > ((size_t)1 << 36)) return fail(PT_ERR_INVALID, "too many rays for one call");  // the work-queue head counts chunks of 64 in 32 bits
-  if (!valid_mode(mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
+  if (!valid_mode(mode) && mode != PT_TRACE_FAST_OCT) return fail(PT_ERR_INVALID, "unknown trace mode");  // callers inside the library may have resolved it already
   mode = effective_mode(s, mode);
   int rc = enter_stream(s, st);
   if (rc != PT_OK) return rc;

@@ -225,10 +225,11 @@ __device__ __forceinline__ void wave_add64(unsigned long long *dst, uint32_t v) 
 // The fast tree's nodes are staged as 7 pieces (6 plane pieces + the references), its gate boxes as 2.
 template <int BLOCK, int MODE>
 __device__ __forceinline__ LdsScene stage_scene(const SceneDev &S, LdsPlan plan, uint32_t &stack_base) {
-  constexpr bool WIDE = mode_wide(MODE);
-  constexpr uint32_t NP = WIDE ? 7u : 4u;   // node pieces kept in LDS
+  constexpr bool WIDE = mode_wide(MODE), OCT = mode_oct(MODE);
+  constexpr uint32_t NP = OCT ? 6u : (WIDE ? 7u : 4u);   // node pieces kept in LDS
   constexpr uint32_t NG = WIDE ? 8u : 4u;   // float4 per node in global memory
-  const float4 *gn = WIDE ? reinterpret_cast<const float4 *>(S.nodes4) : reinterpret_cast<const float4 *>(S.nodes);
+  const float4 *gn = OCT ? reinterpret_cast<const float4 *>(S.nodes8)
+                         : (WIDE ? reinterpret_cast<const float4 *>(S.nodes4) : reinterpret_cast<const float4 *>(S.nodes));
   const float4 *gt = WIDE ? reinterpret_cast<const float4 *>(S.tris4) : reinterpret_cast<const float4 *>(S.tris);
   LdsScene C;
   C.node_base = 0;

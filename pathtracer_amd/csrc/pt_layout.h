@@ -59,6 +59,27 @@ struct alignas(16) Quad4Node {
 };
 static_assert(sizeof(Quad4Node) == 128, "Quad4Node must be 128 bytes");
 
+// Eight-child node of the fast traversal's tree for scenes outside on-chip memory, where a walk's cost is the
+// number of node records it fetches one after the other: eight children resolve in one record, so a descent
+// takes two thirds of the fetches.  96 bytes in use (six float4 pieces) of a 128-byte slot (one cache line):
+//   piece 0  base.x base.y base.z | exps: byte a = biased exponent of the grid step on axis a (step = 2^(byte-127),
+//            0 = the node is exactly flat on that axis and every child plane equals base), byte 3 unused
+//   piece 1  x planes as grid indices, one byte per child: lo[0..7] (two words), hi[0..7] (two words)
+//   piece 2  y planes, piece 3  z planes
+//   piece 4  ref[0..3], piece 5  ref[4..7]   (as in Quad4Node; an unused slot holds an inverted box: lo = 255, hi = 0)
+// A child's plane is base + index * step, rounded outwards by the builder, so the decoded box contains the
+// box the four-child tree stores for the same child (which already carries the margin).  A plane the
+// four-child tree keeps exactly on a flat gate (see pt_fasttree.cpp) stays exact when the whole node is flat
+// there (index 0, plane = base); elsewhere that child gets its unclipped, widened plane instead.
+struct alignas(16) Oct8Node {
+  float base[3];
+  uint32_t exps;
+  uint8_t qx[16], qy[16], qz[16];   // per axis: lo[8] then hi[8]
+  uint32_t ref[8];
+  uint32_t pad[8];
+};
+static_assert(sizeof(Oct8Node) == 128, "Oct8Node must be 128 bytes");
+
 // Box of an internal node of the reference's trees, exactly as given (BVH::Node::box, object.cpp:228-238).
 // The fast traversal accepts a triangle hit only if the ray passes the box of the lowest internal node
 // above that triangle's leaf ("gate"), tested with AABB::intersect's own arithmetic (object.cpp:179-195).
