@@ -317,6 +317,12 @@ struct RayState {
   // at every node.  Such a walk waits on memory, not on the vector unit, and the sixteen registers this saves
   // per lane are a sixth wave per SIMD.
   uint32_t sgn;
+  // eight-child tree (walk_round_oct): the group of sibling nodes being visited (first node index; word = order
+  // flag << 16 | internal-children mask << 8 | mask of those still to visit), the parked group of sibling leaves
+  // (pend = mask of those still to test, pbase = first triangle record, meta bits 0-7 = mask of all leaf
+  // children of that node) and a second group of leaves a lane may reach before the first is tested (meta bits
+  // 8-15 = its all-leaves mask, bits 16-23 = its mask still to test)
+  uint32_t gbase, gw, pbase, qbase, meta;
   HitRec best;
   __device__ __forceinline__ bool done() const { return !live && pend == 0; }
 };
@@ -381,6 +387,7 @@ __device__ __forceinline__ void walk_init(const SceneDev &S, const LdsScene &C, 
   st.sp = 0;
   st.live = true;
   st.found = false;
+  st.gbase = 0u; st.gw = 0u; st.pbase = 0u; st.qbase = 0u; st.meta = 0u;
 }
 
 // The reference's box test (AABB::intersect, object.cpp:179-195) for the gate of a triangle record of the
@@ -470,77 +477,7 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   constexpr bool PRUNE = mode_prunes(MODE), WIDE = mode_wide(MODE);
   if (st.live && !(st.cur & ptl::REF_LEAF)) {
     float far = (PRUNE && !ANY) ? st.cull : __builtin_inff();
-    if constexpr (mode_oct(MODE)) {
-      // Eight children on a grid: a child's plane is base + index * step, so its distance along the ray is
-      // index * (step / d) + (base - o) / d: one fused multiply-add per plane after six products per node.
-      const uint32_t node = st.cur;
-      float4 p0, qx, qy, qz, ra, rb;
-      if (node < C.n_nodes) {
-        const uint32_t at = C.node_base + node, n = C.n_nodes;
-        p0 = lds_f4(at); qx = lds_f4(at + n); qy = lds_f4(at + 2u * n); qz = lds_f4(at + 3u * n);
-        ra = lds_f4(at + 4u * n); rb = lds_f4(at + 5u * n);
-      } else {
-        const size_t at = 8u * (size_t)node;
-        p0 = glb_f4(S.nodes8, at); qx = glb_f4(S.nodes8, at + 1); qy = glb_f4(S.nodes8, at + 2); qz = glb_f4(S.nodes8, at + 3);
-        ra = glb_f4(S.nodes8, at + 4); rb = glb_f4(S.nodes8, at + 5);
-      }
-      if (COUNT) n_boxes += 8;
-      const uint32_t ex = __float_as_uint(p0.w);
-      const float ax = __uint_as_float((ex & 0xffu) << 23) * st.ix;
-      const float ay = __uint_as_float((ex & 0xff00u) << 15) * st.iy;
-      const float az = __uint_as_float((ex & 0xff0000u) << 7) * st.iz;
-      const float mx = (st.sgn & 8u) ? S.margin : 0.0f, my = (st.sgn & 16u) ? S.margin : 0.0f, mz = (st.sgn & 32u) ? S.margin : 0.0f;
-      const float bnx = (p0.x - (st.o.x + mx)) * st.ix, bfx = (p0.x - (st.o.x - mx)) * st.ix;
-      const float bny = (p0.y - (st.o.y + my)) * st.iy, bfy = (p0.y - (st.o.y - my)) * st.iy;
-      const float bnz = (p0.z - (st.o.z + mz)) * st.iz, bfz = (p0.z - (st.o.z - mz)) * st.iz;
-      // index bytes of this ray's near and far planes: words 0-1 hold lo, words 2-3 hi
-      const bool gx = (st.sgn & 1u) != 0u, gy = (st.sgn & 2u) != 0u, gz = (st.sgn & 4u) != 0u;
-      const uint32_t x0 = __float_as_uint(qx.x), x1 = __float_as_uint(qx.y), x2 = __float_as_uint(qx.z), x3 = __float_as_uint(qx.w);
-      const uint32_t y0 = __float_as_uint(qy.x), y1 = __float_as_uint(qy.y), y2 = __float_as_uint(qy.z), y3 = __float_as_uint(qy.w);
-      const uint32_t z0 = __float_as_uint(qz.x), z1 = __float_as_uint(qz.y), z2 = __float_as_uint(qz.z), z3 = __float_as_uint(qz.w);
-      const uint32_t nxw[2] = {gx ? x2 : x0, gx ? x3 : x1}, fxw[2] = {gx ? x0 : x2, gx ? x1 : x3};
-      const uint32_t nyw[2] = {gy ? y2 : y0, gy ? y3 : y1}, fyw[2] = {gy ? y0 : y2, gy ? y1 : y3};
-      const uint32_t nzw[2] = {gz ? z2 : z0, gz ? z3 : z1}, fzw[2] = {gz ? z0 : z2, gz ? z1 : z3};
-      const uint32_t r[8] = {__float_as_uint(ra.x), __float_as_uint(ra.y), __float_as_uint(ra.z), __float_as_uint(ra.w),
-                             __float_as_uint(rb.x), __float_as_uint(rb.y), __float_as_uint(rb.z), __float_as_uint(rb.w)};
-      float tn[8];
-      uint32_t hm = 0u;
-      float km = __builtin_inff();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int w = k >> 2, sh = 8 * (k & 3);
-        const float t0x = __builtin_fmaf((float)((nxw[w] >> sh) & 0xffu), ax, bnx), t1x = __builtin_fmaf((float)((fxw[w] >> sh) & 0xffu), ax, bfx);
-        const float t0y = __builtin_fmaf((float)((nyw[w] >> sh) & 0xffu), ay, bny), t1y = __builtin_fmaf((float)((fyw[w] >> sh) & 0xffu), ay, bfy);
-        const float t0z = __builtin_fmaf((float)((nzw[w] >> sh) & 0xffu), az, bnz), t1z = __builtin_fmaf((float)((fzw[w] >> sh) & 0xffu), az, bfz);
-        // NaN (an infinite 1/d against a plane it cannot order) never restricts
-        const float n_ = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x), t0y), t0z);
-        const float f_ = fminf(fminf(fminf(far, t1x), t1y), t1z);
-        const bool h = f_ >= n_;
-        tn[k] = h ? n_ : __builtin_inff();
-        hm |= h ? (1u << k) : 0u;
-        km = fminf(km, tn[k]);
-      }
-      if (hm != 0u) {
-        // nearest child next; the others wait on the stack, slot 0 on top
-        uint32_t em = 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) em |= (tn[k] == km && ((hm >> k) & 1u)) ? (1u << k) : 0u;
-        const uint32_t c = (uint32_t)__builtin_ctz(em);
-        const uint32_t rest = hm & ~(1u << c);
-#pragma unroll
-        for (int k = 7; k >= 0; --k)
-          if ((rest >> k) & 1u) { push_ref(C, stk, stride, st.sp, r[k]); ++st.sp; }
-        uint32_t nc = r[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) nc = c == (uint32_t)k ? r[k] : nc;
-        st.cur = nc;
-      } else if (st.sp == 0) {
-        st.live = false;
-      } else {
-        --st.sp;
-        st.cur = pop_ref(C, stk, stride, st.sp);
-      }
-    } else if constexpr (WIDE) {
+    if constexpr (WIDE) {
       // A node reached through a REF_NOCULL reference has an ill-conditioned triangle below it, which can
       // report a hit at any distance: its children are entered whenever the ray passes their boxes, however
       // far away those begin.  (Scenes without such triangles have no such references.)
@@ -742,11 +679,148 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   }
 }
 
+// The round of the eight-child tree (scenes outside LDS; pt_layout.h, Oct8Node).  A node names its children by
+// two base indices and a mask, so what waits on the stack is one entry of two words per node (first child, the
+// children still to visit) instead of a reference per child, and a step does no per-child bookkeeping: it tests
+// the eight boxes, forms the masks, and goes on with the first child in the node's own order (children are
+// sorted along the node's longest axis; a ray that runs against that axis takes them from the other end).
+// Leaves are parked and tested by quorum as in walk_round, a node's leaf children as one group.
+template <int MODE, bool ANY, bool COUNT, bool WANT_N>
+__device__ __forceinline__ void walk_round_oct(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
+                                               uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
+  // a lane that holds two groups of parked leaves waits for the triangle tests before it reads another node
+  if (st.live && (st.meta >> 16) == 0u) {
+    const float far = (!ANY) ? st.cull : __builtin_inff();
+    const uint32_t node = st.cur;
+    float4 p0, p1, qx, qy, qz;
+    if (node < C.n_nodes) {
+      const uint32_t at = C.node_base + node, n = C.n_nodes;
+      p0 = lds_f4(at); p1 = lds_f4(at + n); qx = lds_f4(at + 2u * n); qy = lds_f4(at + 3u * n); qz = lds_f4(at + 4u * n);
+    } else {
+      const size_t at = 8u * (size_t)node;
+      p0 = glb_f4(S.nodes8, at); p1 = glb_f4(S.nodes8, at + 1); qx = glb_f4(S.nodes8, at + 2); qy = glb_f4(S.nodes8, at + 3);
+      qz = glb_f4(S.nodes8, at + 4);
+    }
+    if (COUNT) n_boxes += 8;
+    // A child's plane is base + index * step, so its distance along the ray is index * (step / d) + (base - o) / d:
+    // one fused multiply-add per plane after a few products per node.
+    const uint32_t ex = __float_as_uint(p0.w);
+    const float ax = __uint_as_float((ex & 0xffu) << 23) * st.ix;
+    const float ay = __uint_as_float((ex & 0xff00u) << 15) * st.iy;
+    const float az = __uint_as_float((ex & 0xff0000u) << 7) * st.iz;
+    float bnx = (p0.x - st.o.x) * st.ix, bny = (p0.y - st.o.y) * st.iy, bnz = (p0.z - st.o.z) * st.iz;
+    float bfx = bnx, bfy = bny, bfz = bnz;
+    if (__ballot((st.sgn & 0x38u) != 0u) != 0ull) {
+      // some ray of the wave runs parallel to a coordinate plane: its slab on that axis is S.margin wider (walk_init)
+      const float mx = (st.sgn & 8u) ? S.margin : 0.0f, my = (st.sgn & 16u) ? S.margin : 0.0f, mz = (st.sgn & 32u) ? S.margin : 0.0f;
+      bnx = (p0.x - (st.o.x + mx)) * st.ix; bfx = (p0.x - (st.o.x - mx)) * st.ix;
+      bny = (p0.y - (st.o.y + my)) * st.iy; bfy = (p0.y - (st.o.y - my)) * st.iy;
+      bnz = (p0.z - (st.o.z + mz)) * st.iz; bfz = (p0.z - (st.o.z - mz)) * st.iz;
+    }
+    // index bytes of this ray's near and far planes: words 0-1 of an axis' piece hold lo, words 2-3 hi
+    const bool gx = (st.sgn & 1u) != 0u, gy = (st.sgn & 2u) != 0u, gz = (st.sgn & 4u) != 0u;
+    const uint32_t x0 = __float_as_uint(qx.x), x1 = __float_as_uint(qx.y), x2 = __float_as_uint(qx.z), x3 = __float_as_uint(qx.w);
+    const uint32_t y0 = __float_as_uint(qy.x), y1 = __float_as_uint(qy.y), y2 = __float_as_uint(qy.z), y3 = __float_as_uint(qy.w);
+    const uint32_t z0 = __float_as_uint(qz.x), z1 = __float_as_uint(qz.y), z2 = __float_as_uint(qz.z), z3 = __float_as_uint(qz.w);
+    const uint32_t nxw[2] = {gx ? x2 : x0, gx ? x3 : x1}, fxw[2] = {gx ? x0 : x2, gx ? x1 : x3};
+    const uint32_t nyw[2] = {gy ? y2 : y0, gy ? y3 : y1}, fyw[2] = {gy ? y0 : y2, gy ? y1 : y3};
+    const uint32_t nzw[2] = {gz ? z2 : z0, gz ? z3 : z1}, fzw[2] = {gz ? z0 : z2, gz ? z1 : z3};
+    uint32_t hm = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      // two children side by side in packed pairs
+      const int w = k >> 2, s0 = 8 * (k & 3), s1 = s0 + 8;
+      const pt_f2 t0x = __builtin_elementwise_fma(pair2((float)((nxw[w] >> s0) & 0xffu), (float)((nxw[w] >> s1) & 0xffu)), splat2(ax), splat2(bnx));
+      const pt_f2 t0y = __builtin_elementwise_fma(pair2((float)((nyw[w] >> s0) & 0xffu), (float)((nyw[w] >> s1) & 0xffu)), splat2(ay), splat2(bny));
+      const pt_f2 t0z = __builtin_elementwise_fma(pair2((float)((nzw[w] >> s0) & 0xffu), (float)((nzw[w] >> s1) & 0xffu)), splat2(az), splat2(bnz));
+      const pt_f2 t1x = __builtin_elementwise_fma(pair2((float)((fxw[w] >> s0) & 0xffu), (float)((fxw[w] >> s1) & 0xffu)), splat2(ax), splat2(bfx));
+      const pt_f2 t1y = __builtin_elementwise_fma(pair2((float)((fyw[w] >> s0) & 0xffu), (float)((fyw[w] >> s1) & 0xffu)), splat2(ay), splat2(bfy));
+      const pt_f2 t1z = __builtin_elementwise_fma(pair2((float)((fzw[w] >> s0) & 0xffu), (float)((fzw[w] >> s1) & 0xffu)), splat2(az), splat2(bfz));
+      // NaN (an infinite 1/d against a plane it cannot order) never restricts
+      const float na = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x.x), t0y.x), t0z.x), fa = fminf(fminf(fminf(far, t1x.x), t1y.x), t1z.x);
+      const float nb = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x.y), t0y.y), t0z.y), fb = fminf(fminf(fminf(far, t1x.y), t1y.y), t1z.y);
+      hm |= (fa >= na) ? (1u << k) : 0u;
+      hm |= (fb >= nb) ? (2u << k) : 0u;
+    }
+    const uint32_t cbase = __float_as_uint(p1.x), tbase = __float_as_uint(p1.y), masks = __float_as_uint(p1.z);
+    const uint32_t imask = masks & 0xffu, lall = (masks >> 8) & 0xffu;   // internal children; leaf children
+    const uint32_t hn = hm & imask, hl = hm & lall;
+    // visiting order: ascending slots, or descending when the ray runs against the axis the children are sorted on
+    const uint32_t desc = (st.sgn >> ((ex >> 24) & 3u)) & 1u;
+    if (hl != 0u) {
+      if (st.pend == 0u) { st.pend = hl; st.pbase = tbase; st.meta = (st.meta & ~0xffu) | lall; }
+      else { st.qbase = tbase; st.meta = (st.meta & 0xffu) | (lall << 8) | (hl << 16); }
+    }
+    if (hn != 0u) {
+      if ((st.gw & 0xffu) != 0u) {  // the siblings still to visit wait on the stack
+        push_ref(C, stk, stride, st.sp, st.gbase); ++st.sp;
+        push_ref(C, stk, stride, st.sp, st.gw); ++st.sp;
+      }
+      st.gbase = cbase;
+      st.gw = (desc << 16) | (imask << 8) | hn;
+    }
+    if ((st.gw & 0xffu) == 0u) {
+      if (st.sp == 0) {
+        st.live = false;
+      } else {
+        --st.sp; st.gw = pop_ref(C, stk, stride, st.sp);
+        --st.sp; st.gbase = pop_ref(C, stk, stride, st.sp);
+      }
+    }
+    if (st.live) {
+      const uint32_t left = st.gw & 0xffu;
+      const uint32_t k = (st.gw & 0x10000u) ? 31u - (uint32_t)__builtin_clz(left) : (uint32_t)__builtin_ctz(left);
+      st.cur = st.gbase + (uint32_t)__popc((st.gw >> 8) & ((1u << k) - 1u));
+      st.gw &= ~(1u << k);
+    }
+  }
+  const unsigned long long m_pend = __ballot(st.pend != 0u);
+  if (m_pend == 0ull) return;
+  const unsigned long long m_node = __ballot(st.live && (st.meta >> 16) == 0u);
+  bool enough;
+  if (ANY) enough = (uint32_t)__popcll(m_pend) * 64u >= S.quorum_any * (uint32_t)__popcll(__ballot(!st.done()));
+  else enough = (uint32_t)__popcll(m_pend) >= quorum;
+  if ((enough || m_node == 0ull) && st.pend != 0u) {
+    // one leaf of the parked group: two triangle records (a leaf of one triangle is followed by a record no ray hits)
+    const uint32_t k = (uint32_t)__builtin_ctz(st.pend);
+    st.pend &= st.pend - 1u;
+    const uint32_t s0 = st.pbase + 2u * (uint32_t)__popc(st.meta & 0xffu & ((1u << k) - 1u)), s1 = s0 + 1u;
+    if (st.pend == 0u && (st.meta >> 16) != 0u) {  // the second group moves up
+      st.pend = st.meta >> 16;
+      st.pbase = st.qbase;
+      st.meta = (st.meta >> 8) & 0xffu;
+    }
+    if (COUNT) n_tris += 2u;
+    const size_t at0 = 3u * (size_t)s0;
+    const float4 a0 = glb_f4(S.tris4, at0), b0 = glb_f4(S.tris4, at0 + 1), c0 = glb_f4(S.tris4, at0 + 2);
+    const float4 a1 = glb_f4(S.tris4, at0 + 3), b1 = glb_f4(S.tris4, at0 + 4), c1 = glb_f4(S.tris4, at0 + 5);
+    bool h0, h1;
+    pt_f2 t2, u2, v2;
+    tri_test2(a0, b0, c0, a1, b1, c1, st.o, st.d, h0, h1, t2, u2, v2);
+    if (ANY) {
+      // a hit counts only where the reference reaches that triangle's leaf
+      if (h0) { h0 = gate_pass<false>(S, C, st, __float_as_uint(c0.y)); if (COUNT) n_boxes += 1; }
+      if (h1 && !h0) { h1 = gate_pass<false>(S, C, st, __float_as_uint(c1.y)); if (COUNT) n_boxes += 1; }
+      if (h0 || h1) {
+        st.found = true;
+        st.live = false;
+        st.pend = 0u;
+        st.meta = 0u;
+      }
+    } else {
+      consider_hit<MODE, COUNT, WANT_N, false>(S, C, st, n_boxes, h0, t2.x, s0, c0);
+      consider_hit<MODE, COUNT, WANT_N, false>(S, C, st, n_boxes, h1, t2.y, s1, c1);
+      st.cull = st.best.t + (st.best.t * PT_SLACK_REL + PT_SLACK_ABS);
+    }
+  }
+}
+
 // One round.
 template <int MODE, bool ANY, bool COUNT, bool WANT_N, bool RES>
 __device__ __forceinline__ void walk_step(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
                                           uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
-  walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, quorum);
+  if constexpr (mode_oct(MODE)) walk_round_oct<MODE, ANY, COUNT, WANT_N>(S, C, st, stk, stride, n_boxes, n_tris, quorum);
+  else walk_round<MODE, ANY, COUNT, WANT_N, RES>(S, C, st, stk, stride, n_boxes, n_tris, quorum);
 }
 
 // The whole walk for one ray per lane; all lanes return together.

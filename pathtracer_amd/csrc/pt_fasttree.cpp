@@ -339,42 +339,43 @@ struct FastBuilder {
   }
 
   std::vector<uint32_t> leaf_first;  // per binary leaf: its first record in out.tris4
+  bool oct_layout = false;           // the eight-child tree has laid the triangle records out (emit8 ran first)
+
+  void put_record(uint32_t rec) {
+    const TriRec &r = out.tris[rec];
+    TriRec4 q;
+    for (int k = 0; k < 3; ++k) { q.v0[k] = r.v0[k]; q.e1[k] = r.e1[k]; q.e2[k] = r.e2[k]; }
+    q.gate = out.tri_gate[rec];
+    q.mat_id = r.mat_id;
+    q.rank = r.rank;
+    out.tris4.push_back(q);
+    out.tri_id4.push_back(r.tri_id);
+  }
 
   void emit() {
-    test_boxes();
     const std::vector<uint32_t> seq = sequence(wide, wide_of, 1280);
     std::vector<uint32_t> newidx(wide.size(), 0);
     for (uint32_t j = 0; j < seq.size(); ++j) newidx[seq[j]] = j;
 
-    // triangle records in the order the leaves are met
-    out.tris4.clear();
-    out.tri_id4.clear();
-    out.tris4.reserve((size_t)n + 1);
-    out.tri_id4.reserve((size_t)n + 1);
-    auto put = [&](uint32_t rec) {
-      const TriRec &r = out.tris[rec];
-      TriRec4 q;
-      for (int k = 0; k < 3; ++k) { q.v0[k] = r.v0[k]; q.e1[k] = r.e1[k]; q.e2[k] = r.e2[k]; }
-      q.gate = out.tri_gate[rec];
-      q.mat_id = r.mat_id;
-      q.rank = r.rank;
-      out.tris4.push_back(q);
-      out.tri_id4.push_back(r.tri_id);
-    };
-    leaf_first.assign(bn.size(), 0);
-    for (uint32_t j = 0; j < seq.size(); ++j) {
-      const Wide &w = wide[seq[j]];
-      for (int k = 0; k < w.n_child; ++k) {
-        const BinNode &c = bn[w.child[k]];
-        if (c.count == 0) continue;
-        leaf_first[w.child[k]] = (uint32_t)out.tris4.size();
-        for (uint32_t t = 0; t < c.count; ++t) {
-          put(order[c.first + t]);
+    if (!oct_layout) {
+      // triangle records in the order the leaves are met
+      out.tris4.clear();
+      out.tri_id4.clear();
+      out.tris4.reserve((size_t)n + 1);
+      out.tri_id4.reserve((size_t)n + 1);
+      leaf_first.assign(bn.size(), 0);
+      for (uint32_t j = 0; j < seq.size(); ++j) {
+        const Wide &w = wide[seq[j]];
+        for (int k = 0; k < w.n_child; ++k) {
+          const BinNode &c = bn[w.child[k]];
+          if (c.count == 0) continue;
+          leaf_first[w.child[k]] = (uint32_t)out.tris4.size();
+          for (uint32_t t = 0; t < c.count; ++t) put_record(order[c.first + t]);
         }
       }
+      put_record(n);  // the degenerate triangle no ray hits
     }
-    const uint32_t filler = (uint32_t)out.tris4.size();
-    put(n);  // the degenerate triangle no ray hits
+    const uint32_t filler = (uint32_t)out.tris4.size() - 1;
 
     out.nodes4.assign(seq.size(), Quad4Node());
     for (uint32_t j = 0; j < seq.size(); ++j) {
@@ -425,23 +426,57 @@ struct FastBuilder {
     }
   }
 
-  // The eight-child form of the same binary tree (pt_layout.h, Oct8Node), over the same triangle records.
+  // The eight-child form of the same binary tree (pt_layout.h, Oct8Node).  It names children by position, so it
+  // decides where nodes and triangle records go: a node's internal children get consecutive node indices, its
+  // leaf children consecutive pairs of triangle records (the four-child tree then points into the same records).
+  // Built only for a scene that will not sit in LDS as a whole, and only when every box is finite and no
+  // triangle is ill-conditioned (boxes bounded by a gate alone, or by nothing, do not go on a grid).
   void emit8() {
     out.nodes8.clear();
     out.max_depth8 = 0;
-    if (out.n_ill != 0) return;  // boxes bounded by gates alone (or by nothing) do not go on a grid
+    oct_layout = false;
+    if (out.n_ill != 0) return;
+    const size_t lds_bytes = 112 * wide.size() + 48 * ((size_t)n + 1) + 32 * out.gates.size();
+    if (lds_bytes <= 88 * 1024 && !std::getenv("PT_OCT_ALWAYS")) return;
     for (const Box3 &b : tb)
       for (int k = 0; k < 3; ++k)
         if (!(b.lo[k] <= b.hi[k]) || !std::isfinite(b.lo[k]) || !std::isfinite(b.hi[k])) return;
-    const std::vector<uint32_t> seq = sequence(wide8, wide_of8, 600);
-    std::vector<uint32_t> newidx(wide8.size(), 0);
-    for (uint32_t j = 0; j < seq.size(); ++j) newidx[seq[j]] = j;
-    const uint32_t filler = (uint32_t)out.tris4.size() - 1;
-    out.nodes8.assign(seq.size(), Oct8Node());
-    for (uint32_t j = 0; j < seq.size(); ++j) {
-      const Wide &w = wide8[seq[j]];
+    for (const Box3 &b : tbw)
+      for (int k = 0; k < 3; ++k)
+        if (!std::isfinite(b.lo[k]) || !std::isfinite(b.hi[k])) return;
+    if (wide8.size() > 0x3fffffffu) return;
+    oct_layout = true;
+    out.tris4.clear();
+    out.tri_id4.clear();
+    out.tris4.reserve((size_t)n + n / 4 + 2);
+    out.tri_id4.reserve((size_t)n + n / 4 + 2);
+    leaf_first.assign(bn.size(), 0);
+    out.nodes8.assign(wide8.size(), Oct8Node());
+    // nodes are numbered as their parents are laid out: the top of the tree breadth-first (kept in LDS), the rest
+    // depth-first, so that a node's children follow it closely
+    std::vector<uint32_t> wide_at(wide8.size(), 0);   // nodes8 index -> wide8 index
+    std::vector<uint32_t> depth_of(wide8.size(), 1);
+    std::deque<uint32_t> work;                         // nodes8 indices whose children are not laid out yet
+    uint32_t next_node = 1, deepest = 1;
+    work.push_back(0);
+    while (!work.empty()) {
+      uint32_t j;
+      if (next_node < 600) { j = work.front(); work.pop_front(); }
+      else { j = work.back(); work.pop_back(); }
+      Wide w = wide8[wide_at[j]];
       Oct8Node &o = out.nodes8[j];
       memset(&o, 0, sizeof(o));
+      // node box and the axis its children are sorted on
+      Box3 nb;
+      nb.clear();
+      for (int k = 0; k < w.n_child; ++k) nb.grow(tb[w.child[k]]);
+      int axis = 0;
+      for (int a = 1; a < 3; ++a)
+        if (nb.hi[a] - nb.lo[a] > nb.hi[axis] - nb.lo[axis]) axis = a;
+      std::stable_sort(w.child, w.child + w.n_child, [&](uint32_t x, uint32_t y) {
+        return tb[x].lo[axis] + tb[x].hi[axis] < tb[y].lo[axis] + tb[y].hi[axis];
+      });
+      o.exps = (uint32_t)axis << 24;
       uint8_t *q[3] = {o.qx, o.qy, o.qz};
       for (int a = 0; a < 3; ++a) {
         // exactly flat node: every child is flat on this axis at one and the same plane
@@ -453,8 +488,7 @@ struct FastBuilder {
         }
         if (flat) {
           o.base[a] = v;
-          for (int k = 0; k < 8; ++k) { q[a][k] = k < w.n_child ? 0 : 255; q[a][8 + k] = 0; }
-          continue;  // exponent byte 0
+          continue;  // exponent byte 0, every index 0
         }
         // a child that is flat here keeps its margin instead (its exact plane is not on the grid)
         double lo[8], hi[8], nlo = INFINITY, nhi = -INFINITY;
@@ -466,14 +500,13 @@ struct FastBuilder {
           nlo = std::min(nlo, lo[k]);
           nhi = std::max(nhi, hi[k]);
         }
-        const float base = (float)nlo <= nlo ? (float)nlo : std::nextafterf((float)nlo, -INFINITY);
+        const float base = (float)nlo;  // exact: nlo is one of the float planes
         o.base[a] = base;
         int e = -126;
         while (e < 127 && (double)base + 254.0 * std::ldexp(1.0, e) < nhi) ++e;
         const double step = std::ldexp(1.0, e);
         o.exps |= (uint32_t)(e + 127) << (8 * a);
-        for (int k = 0; k < 8; ++k) {
-          if (k >= w.n_child) { q[a][k] = 255; q[a][8 + k] = 0; continue; }
+        for (int k = 0; k < w.n_child; ++k) {
           double ql = std::floor((lo[k] - (double)base) / step), qh = std::ceil((hi[k] - (double)base) / step);
           while (ql > 0 && (double)base + ql * step > lo[k]) ql -= 1;
           while ((double)base + qh * step < hi[k]) qh += 1;
@@ -483,25 +516,31 @@ struct FastBuilder {
           q[a][8 + k] = (uint8_t)qh;
         }
       }
-      for (int k = 0; k < 8; ++k) {
-        if (k >= w.n_child) { o.ref[k] = REF_LEAF | filler; continue; }
+      o.child_base = next_node;
+      o.tri_base = (uint32_t)out.tris4.size();
+      uint32_t imask = 0, lmask = 0;
+      for (int k = 0; k < w.n_child; ++k) {
         const BinNode &c = bn[w.child[k]];
-        if (c.count > 0) o.ref[k] = REF_LEAF | ((c.count - 1) << 28) | leaf_first[w.child[k]];
-        else o.ref[k] = newidx[wide_of8[w.child[k]]];
+        if (c.count > 0) {
+          lmask |= 1u << k;
+          leaf_first[w.child[k]] = (uint32_t)out.tris4.size();
+          for (uint32_t t = 0; t < c.count; ++t) put_record(order[c.first + t]);
+          if (c.count == 1) put_record(n);  // a record no ray hits fills the pair
+        } else {
+          imask |= 1u << k;
+          wide_at[next_node] = wide_of8[w.child[k]];
+          depth_of[next_node] = depth_of[j] + 1;
+          if (depth_of[next_node] > deepest) deepest = depth_of[next_node];
+          ++next_node;
+        }
       }
+      o.masks = imask | (lmask << 8);
+      // the first child is laid out next in the depth-first part (the work list is then taken from its end)
+      if (next_node < 600) for (uint32_t c = o.child_base; c < next_node; ++c) work.push_back(c);
+      else for (uint32_t c = next_node; c-- > o.child_base;) work.push_back(c);
     }
-    uint32_t deepest = 1;
-    std::vector<std::pair<uint32_t, uint32_t>> walk;  // node, depth
-    walk.push_back(std::make_pair(0u, 1u));
-    while (!walk.empty()) {
-      const std::pair<uint32_t, uint32_t> e = walk.back();
-      walk.pop_back();
-      if (e.second > deepest) deepest = e.second;
-      const Oct8Node &o = out.nodes8[e.first];
-      for (int k = 0; k < 8; ++k)
-        if (!(o.ref[k] & REF_LEAF)) walk.push_back(std::make_pair(o.ref[k], e.second + 1));
-    }
-    out.max_depth8 = 7 * deepest + 2;  // up to seven siblings left behind per level
+    put_record(n);  // the degenerate triangle no ray hits, at the end as in the other layout
+    out.max_depth8 = 2 * (deepest + 1);  // one entry of two words may wait per level
   }
 
   void run() {
@@ -546,8 +585,9 @@ struct FastBuilder {
       collapse(4, wide, wide_of);
       collapse(8, wide8, wide_of8);
     }
-    emit();
+    test_boxes();
     emit8();
+    emit();
   }
 };
 

@@ -608,7 +608,7 @@ int check_fast_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) 
     }
   }
   for (uint32_t t = 0; t + 1 < n_tris; ++t)
-    if (!seen[t]) { err = "fast tree: triangle in no leaf"; return PT_ERR_INVALID; }
+    if (!seen[t] && f.tri_id4[t] != 0xffffffffu) { err = "fast tree: triangle in no leaf"; return PT_ERR_INVALID; }  // (a record that fills a pair of the eight-child tree is in none)
   for (size_t i = 0; i < f.nodes4.size(); ++i)
     if (!node_seen[i]) { err = "fast tree: unreachable node"; return PT_ERR_INVALID; }
   return PT_OK;
@@ -619,11 +619,12 @@ double oct_plane(const Oct8Node &n, int axis, uint32_t index) {
   return e == 0 ? (double)n.base[axis] : (double)n.base[axis] + (double)index * std::ldexp(1.0, (int)e - 127);
 }
 
-// Invariants of the eight-child tree: every node reachable once, every triangle record in exactly one leaf, and
-// every box on the way down to a leaf (each decoded on its own node's grid, so a child's may reach outside its
-// parent's) around that leaf's triangles with the margin the fast tree's leaves keep: at least half of it on
-// every axis, except where a plane is exactly flat (the node's exponent byte is 0) and the triangles lie in
-// that very plane.  The test is made against the intersection of the boxes on the path.
+// Invariants of the eight-child tree: every node reachable once, every triangle record in exactly one leaf
+// (the records that fill a one-triangle leaf's pair aside), and every box on the way down to a leaf (each decoded
+// on its own node's grid, so a child's may reach outside its parent's) around that leaf's triangles with the
+// margin the fast tree's leaves keep: at least half of it on every axis, except where a plane is exactly flat
+// (the node's exponent byte is 0) and the triangles lie in that very plane.  The test is made against the
+// intersection of the boxes on the path.
 int check_oct_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) {
   if (f.nodes8.empty()) return PT_OK;
   const uint32_t n_tris = (uint32_t)f.tris4.size();
@@ -642,26 +643,29 @@ int check_oct_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) {
     node_seen[it.node] = 1;
     const Oct8Node &q = f.nodes8[it.node];
     const uint8_t *qq[3] = {q.qx, q.qy, q.qz};
+    const uint32_t imask = q.masks & 0xffu, lmask = (q.masks >> 8) & 0xffu;
+    if ((imask & lmask) != 0 || (q.masks >> 16) != 0 || ((q.exps >> 24) & 0xffu) > 2) { err = "eight-child tree: malformed masks"; return PT_ERR_INVALID; }
+    uint32_t n_int = 0, n_leaf = 0;
     for (int c = 0; c < 8; ++c) {
+      if (!(((imask | lmask) >> c) & 1u)) continue;
       double lo[3], hi[3];
-      bool unused = false, flat[3];
+      bool flat[3];
       for (int k = 0; k < 3; ++k) {
+        if (qq[k][c] > qq[k][8 + c]) { err = "eight-child tree: inverted box"; return PT_ERR_INVALID; }
         lo[k] = std::fmax(it.lo[k], oct_plane(q, k, qq[k][c]));
         hi[k] = std::fmin(it.hi[k], oct_plane(q, k, qq[k][8 + c]));
         flat[k] = it.flat[k] || ((q.exps >> (8 * k)) & 0xffu) == 0;
-        if (qq[k][c] > qq[k][8 + c]) unused = true;
       }
-      if (unused || q.ref[c] == (REF_LEAF | (n_tris - 1))) {
-        if (q.ref[c] != (REF_LEAF | (n_tris - 1))) { err = "eight-child tree: inverted box on a used slot"; return PT_ERR_INVALID; }
-        continue;
-      }
-      if (q.ref[c] & REF_NOCULL) { err = "eight-child tree: unexpected reference flag"; return PT_ERR_INVALID; }
-      if (q.ref[c] & REF_LEAF) {
-        const uint32_t first = q.ref[c] & REF_FIRST_MASK, cnt = ((q.ref[c] >> 28) & 1u) + 1u;
-        if (first + cnt > n_tris - 1) { err = "eight-child tree: leaf range out of range"; return PT_ERR_INVALID; }
-        for (uint32_t t = first; t < first + cnt; ++t) {
-          if (seen[t]) { err = "eight-child tree: triangle in two leaves"; return PT_ERR_INVALID; }
+      if ((lmask >> c) & 1u) {
+        const uint32_t first = q.tri_base + 2u * n_leaf;
+        ++n_leaf;
+        if ((uint64_t)first + 2 > n_tris - 1) { err = "eight-child tree: leaf range out of range"; return PT_ERR_INVALID; }
+        uint32_t real = 0;
+        for (uint32_t t = first; t < first + 2; ++t) {
+          if (seen[t]) { err = "eight-child tree: triangle record in two leaves"; return PT_ERR_INVALID; }
           seen[t] = 1;
+          if (f.tri_id4[t] == 0xffffffffu) continue;  // fills the pair of a one-triangle leaf
+          ++real;
           const float *p = d.tri_verts + (size_t)f.tri_id4[t] * 9;
           if (triangle_is_ill_conditioned(p)) { err = "eight-child tree: built over an ill-conditioned triangle"; return PT_ERR_INVALID; }
           for (int k = 0; k < 3; ++k) {
@@ -674,17 +678,20 @@ int check_oct_tree(const PtSceneDesc &d, const FlatScene &f, std::string &err) {
               return PT_ERR_INVALID;
             }
           }
+          if (f.tris4[t].gate != NO_GATE && f.tris4[t].gate >= f.gates.size()) { err = "eight-child tree: gate index out of range"; return PT_ERR_INVALID; }
         }
+        if (real == 0 || f.tri_id4[first] == 0xffffffffu) { err = "eight-child tree: empty leaf"; return PT_ERR_INVALID; }
       } else {
         Item ch;
-        ch.node = q.ref[c];
+        ch.node = q.child_base + n_int;
+        ++n_int;
         for (int k = 0; k < 3; ++k) { ch.lo[k] = lo[k]; ch.hi[k] = hi[k]; ch.flat[k] = flat[k]; }
         todo.push_back(ch);
       }
     }
   }
   for (uint32_t t = 0; t + 1 < n_tris; ++t)
-    if (!seen[t]) { err = "eight-child tree: triangle in no leaf"; return PT_ERR_INVALID; }
+    if (!seen[t]) { err = "eight-child tree: triangle record in no leaf"; return PT_ERR_INVALID; }
   for (size_t i = 0; i < f.nodes8.size(); ++i)
     if (!node_seen[i]) { err = "eight-child tree: unreachable node"; return PT_ERR_INVALID; }
   return PT_OK;

@@ -198,14 +198,14 @@ static int make_plan(PtScene *s, int kind) {
   const uint32_t depth = oct ? s->max_depth8 : (wide ? s->max_depth4 : s->max_depth);
   const uint32_t n_nodes = oct ? s->dev.n_nodes8 : (wide ? s->dev.n_nodes4 : s->dev.n_nodes), n_tris = wide ? s->dev.n_tris4 : s->dev.n_tris;
   // the fast tree's nodes are kept without their padding pieces
-  const size_t node_lds = oct ? 6 * 16 : (wide ? 7 * 16 : sizeof(ptl::WideNode));
+  const size_t node_lds = oct ? 5 * 16 : (wide ? 7 * 16 : sizeof(ptl::WideNode));
   const size_t gate_bytes = wide ? (size_t)s->dev.n_gates * sizeof(ptl::GateBox) : 0;
   p.stack = stack_class(depth);
   if (!p.stack) return fail(PT_ERR_UNSUPPORTED, "tree deeper than 128 levels");
   // deeper trees keep only the first entries in LDS and spill the rest to global memory, so
   // that LDS still holds 16 waves per CU and a useful part of the tree
   int cap = wide ? 16 : 24;  // a descent of the four-child tree rarely holds more than a dozen entries
-  if (oct) cap = 24;         // up to seven siblings wait per level of the eight-child tree
+  if (oct) cap = 24;         // two words per level of the eight-child tree
   if (const char *e = std::getenv("PT_STACK_CAP")) {  // tuning knob
     const int c = std::atoi(e);
     if (c >= 4 && c <= 128) cap = c;

@@ -226,7 +226,7 @@ __device__ __forceinline__ void wave_add64(unsigned long long *dst, uint32_t v) 
 template <int BLOCK, int MODE>
 __device__ __forceinline__ LdsScene stage_scene(const SceneDev &S, LdsPlan plan, uint32_t &stack_base) {
   constexpr bool WIDE = mode_wide(MODE), OCT = mode_oct(MODE);
-  constexpr uint32_t NP = OCT ? 6u : (WIDE ? 7u : 4u);   // node pieces kept in LDS
+  constexpr uint32_t NP = OCT ? 5u : (WIDE ? 7u : 4u);   // node pieces kept in LDS
   constexpr uint32_t NG = WIDE ? 8u : 4u;   // float4 per node in global memory
   const float4 *gn = OCT ? reinterpret_cast<const float4 *>(S.nodes8)
                          : (WIDE ? reinterpret_cast<const float4 *>(S.nodes4) : reinterpret_cast<const float4 *>(S.nodes));
@@ -331,6 +331,8 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
     RayState st;
     st.live = false;
     st.pend = 0;
+    st.meta = 0;
+    st.gw = 0;
     for (;;) {
       const unsigned long long m_busy = __ballot(busy);
       const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);

@@ -61,12 +61,16 @@ static_assert(sizeof(Quad4Node) == 128, "Quad4Node must be 128 bytes");
 
 // Eight-child node of the fast traversal's tree for scenes outside on-chip memory, where a walk's cost is the
 // number of node records it fetches one after the other: eight children resolve in one record, so a descent
-// takes two thirds of the fetches.  96 bytes in use (six float4 pieces) of a 128-byte slot (one cache line):
+// takes fewer fetches.  80 bytes in use (five float4 pieces) of a 128-byte slot (one cache line):
 //   piece 0  base.x base.y base.z | exps: byte a = biased exponent of the grid step on axis a (step = 2^(byte-127),
-//            0 = the node is exactly flat on that axis and every child plane equals base), byte 3 unused
-//   piece 1  x planes as grid indices, one byte per child: lo[0..7] (two words), hi[0..7] (two words)
-//   piece 2  y planes, piece 3  z planes
-//   piece 4  ref[0..3], piece 5  ref[4..7]   (as in Quad4Node; an unused slot holds an inverted box: lo = 255, hi = 0)
+//            0 = the node is exactly flat on that axis and every child plane equals base), byte 3 = the axis the
+//            children are sorted on (ascending centres)
+//   piece 1  child_base | tri_base | masks (bits 0-7: slot holds an internal node, bits 8-15: slot holds a leaf) | -
+//   piece 2  x planes as grid indices, one byte per child: lo[0..7] (two words), hi[0..7] (two words)
+//   piece 3  y planes, piece 4  z planes
+// Children are named by position: the internal children of a node are the nodes child_base, child_base + 1, ... in
+// slot order, its leaf children the triangle records tri_base, tri_base + 2, ... (every leaf takes two records; a
+// leaf of one triangle is followed by a record no ray hits).  An unused slot is in neither mask.
 // A child's plane is base + index * step, rounded outwards by the builder, so the decoded box contains the
 // box the four-child tree stores for the same child (which already carries the margin).  A plane the
 // four-child tree keeps exactly on a flat gate (see pt_fasttree.cpp) stays exact when the whole node is flat
@@ -74,9 +78,9 @@ static_assert(sizeof(Quad4Node) == 128, "Quad4Node must be 128 bytes");
 struct alignas(16) Oct8Node {
   float base[3];
   uint32_t exps;
+  uint32_t child_base, tri_base, masks, pad0;
   uint8_t qx[16], qy[16], qz[16];   // per axis: lo[8] then hi[8]
-  uint32_t ref[8];
-  uint32_t pad[8];
+  uint32_t pad[12];
 };
 static_assert(sizeof(Oct8Node) == 128, "Oct8Node must be 128 bytes");
 
