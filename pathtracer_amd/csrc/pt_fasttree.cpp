@@ -242,6 +242,79 @@ struct FastBuilder {
     }
   }
 
+  // The same collapse by dynamic programming over the binary tree: the set of wide nodes that minimises the
+  // summed surface area of the wide nodes, i.e. the expected number of node visits of a random ray, for the
+  // given width (leaves stay what they are).  cost[n][i] is the least cost of the subtree of binary node n
+  // cut into at most i pieces that hang side by side in one wide node; a piece is a leaf or a wide node of its
+  // own (its area plus the best cut of its two halves into at most `width` pieces).  The greedy collapse fills the
+  // upper node of a small subtree and leaves its children nearly empty (4 of 8 slots in use on average);
+  // this one fills the nodes next to the leaves.
+  void collapse_optimal(int width, std::vector<Wide> &wide, std::vector<uint32_t> &wide_of) {
+    const int W = width;
+    const size_t nb = bn.size();
+    std::vector<float> cost(nb * (size_t)W, INFINITY);        // [n][i-1], i = 1..W-1 pieces (index W-1 unused)
+    std::vector<uint8_t> cut(nb * (size_t)W, 0);              // [n][i-1]: pieces given to the left half (0: same as i-1 pieces)
+    std::vector<uint8_t> cut_node(nb, 0);                     // pieces given to the left half when n heads a wide node
+    auto C = [&](uint32_t n, int i) -> float & { return cost[(size_t)n * W + (i - 1)]; };
+    for (size_t n = nb; n-- > 0;) {  // children were created after their parent
+      const BinNode &b = bn[n];
+      if (b.count > 0) {
+        for (int i = 1; i < W; ++i) C((uint32_t)n, i) = 0.0f;  // a leaf costs the same wherever it hangs
+        continue;
+      }
+      const uint32_t l = b.left, r = b.right;
+      // as a wide node of its own: its area + the best cut of the halves into at most W pieces
+      float best = INFINITY;
+      int best_k = 1;
+      for (int k = 1; k < W; ++k) {
+        const float c = C(l, k) + C(r, W - k);
+        if (c < best) { best = c; best_k = k; }
+      }
+      cut_node[n] = (uint8_t)best_k;
+      C((uint32_t)n, 1) = best + b.box.area();
+      for (int i = 2; i < W; ++i) {
+        float bi = C((uint32_t)n, i - 1);
+        int bk = 0;
+        for (int k = 1; k < i; ++k) {
+          const float c = C(l, k) + C(r, i - k);
+          if (c < bi) { bi = c; bk = k; }
+        }
+        C((uint32_t)n, i) = bi;
+        cut[n * (size_t)W + (i - 1)] = (uint8_t)bk;
+      }
+    }
+    wide.clear();
+    wide_of.assign(nb, 0xffffffffu);
+    std::vector<uint32_t> todo;
+    todo.push_back(0);
+    struct Part { uint32_t n; int i; };
+    std::vector<Part> parts;
+    while (!todo.empty()) {
+      const uint32_t head = todo.back();
+      todo.pop_back();
+      Wide w;
+      w.n_child = 0;
+      parts.clear();
+      parts.push_back(Part{bn[head].left, (int)cut_node[head]});
+      parts.push_back(Part{bn[head].right, W - (int)cut_node[head]});
+      while (!parts.empty()) {
+        Part p = parts.back();
+        parts.pop_back();
+        if (bn[p.n].count > 0) { w.child[w.n_child++] = p.n; continue; }
+        if (p.i >= W) p.i = W - 1;
+        while (p.i > 1 && cut[(size_t)p.n * W + (p.i - 1)] == 0) --p.i;  // fewer pieces were as good
+        if (p.i == 1) { w.child[w.n_child++] = p.n; continue; }    // hangs here as a wide node of its own
+        const int k = cut[(size_t)p.n * W + (p.i - 1)];
+        parts.push_back(Part{bn[p.n].right, p.i - k});
+        parts.push_back(Part{bn[p.n].left, k});
+      }
+      wide_of[head] = (uint32_t)wide.size();
+      wide.push_back(w);
+      for (int k = 0; k < w.n_child; ++k)
+        if (bn[w.child[k]].count == 0) todo.push_back(w.child[k]);
+    }
+  }
+
   // Boxes the kernels test: a leaf's exact bounds widened by the margin and then clipped to the bounds of its
   // triangles' gate boxes (a ray that misses the gate cannot produce an accepted hit, and the clipped planes
   // are the reference's own, tested with the reference's arithmetic: a flat wall keeps its flat box and a ray
@@ -583,7 +656,8 @@ struct FastBuilder {
       wide_of8 = wide_of;
     } else {
       collapse(4, wide, wide_of);
-      collapse(8, wide8, wide_of8);
+      if (std::getenv("PT_OCT_GREEDY")) collapse(8, wide8, wide_of8);  // tuning knob: the simple collapse, for comparison
+      else collapse_optimal(8, wide8, wide_of8);
     }
     test_boxes();
     emit8();
