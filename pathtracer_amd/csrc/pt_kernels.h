@@ -404,7 +404,7 @@ __device__ __forceinline__ bool survives(const SceneDev &S, const PathFrame &F, 
 // 64-bit mask of each chunk, so that the survivors' places in the next queue are known before
 // the shading kernel writes them.
 #ifndef PT_TRACE_OCC
-#define PT_TRACE_OCC 5
+#define PT_TRACE_OCC 6
 #endif
 // Outside LDS in 256-thread workgroups the walk waits on memory and a fifth wave per SIMD is worth more than
 // the registers beyond 96 (measured: the same kernel at 4 waves per SIMD walks a quarter fewer rays per second).
@@ -583,7 +583,7 @@ struct ShadowDev {
 };
 
 #ifndef PT_SHADOW_OCC
-#define PT_SHADOW_OCC 5
+#define PT_SHADOW_OCC 6
 #endif
 // Outside LDS in 256-thread workgroups: the register count is capped for five waves per SIMD (96 registers).
 template <int MODE, int BLOCK, bool COUNT, bool RES>
