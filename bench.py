@@ -155,7 +155,8 @@ def load_pmc(name):
 def roofline_block(name, mode, spp, info, prof, counts, count_spp):
     """Roofline of the dominant kernel, k_trace_queue (closest hit).  Time: HIP events around every launch on
     the launch stream, measured in this run.  `achieved`: the algorithmic bytes of the traversal actually run
-    (28 B per child box tested in the fast tree's 112-byte nodes of four, or 32 B in the reference-shaped tree;
+    (28 B per child box tested in the fast tree's 112-byte nodes of four, 10 B in its 80-byte nodes of eight, or 32 B
+    in the reference-shaped tree;
     36 B per triangle tested; 53 B of queue traffic per ray: 32 B ray record in, 21 B hit record out; the box
     and triangle counts come from the instrumented pass of this run) per second.  For a scene that lives in LDS
     only the 53 B per ray can come from HBM, and that is what is priced.  `traffic`: HBM-side bytes per launch
@@ -188,7 +189,10 @@ def roofline_block(name, mode, spp, info, prof, counts, count_spp):
                             "how": pmc.get("hbm_bytes_how")}
     if counts is not None and counts.rays_closest:
         nb, nt, nr = counts.node_boxes, counts.tri_tests, counts.rays_closest
-        box_bytes = 28.0 if mode == "fast" else 32.0
+        # per child box: 28 B in the four-child tree (112-byte node), 10 B in the eight-child tree (80-byte node)
+        oct_tree = mode == "fast" and not resident and info.get("n_oct_nodes", 0) > 0
+        box_bytes = (10.0 if oct_tree else 28.0) if mode == "fast" else 32.0
+        roof["tree"] = "eight-child, boxes on an 8-bit grid" if oct_tree else ("four-child" if mode == "fast" else "reference-shaped")
         per_ray = (box_bytes * nb + 36.0 * nt) / nr + 53.0
         roof["node_boxes_per_ray"] = nb / nr
         roof["tri_tests_per_ray"] = nt / nr

@@ -132,6 +132,8 @@ struct PtScene {
   uint32_t *acnt = nullptr;
   // Asynchronous calls share the counter block and the workspace, so work enqueued on a new stream
   // waits for what the previous call left on the old one.
+  float *d_stage = nullptr;                // device staging of the host-pointer ray queries, kept between calls (grow only)
+  size_t stage_floats = 0;
   hipEvent_t ev_last = nullptr;
   hipStream_t last_stream = nullptr;
   bool has_last = false;
@@ -724,6 +726,7 @@ void pt_scene_free(PtScene *s) {
   if (s->d_tri_id4) (void)hipFree(s->d_tri_id4);
   if (s->d_gates) (void)hipFree(s->d_gates);
   if (s->d_tri_uv4) (void)hipFree(s->d_tri_uv4);
+  if (s->d_stage) (void)hipFree(s->d_stage);
   if (s->d_cnt) (void)hipFree(s->d_cnt);
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->h_cnt) (void)hipHostFree(s->h_cnt);
@@ -934,6 +937,22 @@ int pt_trace_closest_dev(PtScene *s, size_t n, const float *ox, const float *oy,
   return trace_dev(s, n, ox, oy, oz, dx, dy, dz, t, tri, u, v, mode, (hipStream_t)stream, false);
 }
 
+// Device staging for the host-pointer ray queries: kept with the scene and only ever grown, so that a caller
+// that asks for a few rays at a time (Scene::castray is one ray per call in the reference) does not pay an
+// allocation per call.
+static int stage_buffer(PtScene *s, size_t floats, float **out) {
+  if (s->stage_floats < floats) {
+    if (s->d_stage) (void)hipFree(s->d_stage);
+    s->d_stage = nullptr;
+    s->stage_floats = 0;
+    const size_t want = floats < 65536 ? 65536 : floats;
+    HIP_TRY(hipMalloc(&s->d_stage, want * sizeof(float)));
+    s->stage_floats = want;
+  }
+  *out = s->d_stage;
+  return PT_OK;
+}
+
 static int read_stats4(PtScene *s, uint64_t out[4]) {
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
@@ -985,8 +1004,8 @@ int pt_trace_closest(PtScene *s, size_t n, const float *ox, const float *oy, con
   float *buf = nullptr;
   const size_t m = n < chunk ? n : chunk;
   if (m == 0) return PT_OK;
-  HIP_TRY(hipMalloc(&buf, 10 * m * sizeof(float)));
-  int rc = PT_OK;
+  int rc = stage_buffer(s, 10 * m, &buf);
+  if (rc != PT_OK) return rc;
   for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
     const size_t k = (n - off) < chunk ? (n - off) : chunk;
     const float *src[6] = {ox + off, oy + off, oz + off, dx + off, dy + off, dz + off};
@@ -1004,7 +1023,6 @@ int pt_trace_closest(PtScene *s, size_t n, const float *ox, const float *oy, con
     if (e == hipSuccess && v) e = hipMemcpy(v + off, buf + 9 * m, k * sizeof(float), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
   }
-  (void)hipFree(buf);
   return rc;
 }
 
@@ -1020,9 +1038,10 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
   const size_t m = n < chunk ? n : chunk;
   if (m == 0) return PT_OK;
   float *buf = nullptr;
-  HIP_TRY(hipMalloc(&buf, 7 * m * sizeof(float)));
-  int rc = enter_stream(s, nullptr);
-  if (rc != PT_OK) { (void)hipFree(buf); return rc; }
+  int rc = stage_buffer(s, 7 * m, &buf);
+  if (rc != PT_OK) return rc;
+  rc = enter_stream(s, nullptr);
+  if (rc != PT_OK) return rc;
   s->has_last = false;  // these calls end with hipDeviceSynchronize: nothing is left in flight
   for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
     const size_t k = (n - off) < chunk ? (n - off) : chunk;
@@ -1047,7 +1066,6 @@ int pt_trace_any(PtScene *s, size_t n, const float *ox, const float *oy, const f
     if (e == hipSuccess) e = hipMemcpy(hit + off, dh, k, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
   }
-  (void)hipFree(buf);
   return rc;
 }
 
@@ -1063,9 +1081,10 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
   const size_t m = n < chunk ? n : chunk;
   if (m == 0) return PT_OK;
   float *buf = nullptr;
-  HIP_TRY(hipMalloc(&buf, 7 * m * sizeof(float)));
-  int rc = enter_stream(s, nullptr);
-  if (rc != PT_OK) { (void)hipFree(buf); return rc; }
+  int rc = stage_buffer(s, 7 * m, &buf);
+  if (rc != PT_OK) return rc;
+  rc = enter_stream(s, nullptr);
+  if (rc != PT_OK) return rc;
   s->has_last = false;  // these calls end with hipDeviceSynchronize: nothing is left in flight
   for (size_t off = 0; off < n && rc == PT_OK; off += chunk) {
     const size_t k = (n - off) < chunk ? (n - off) : chunk;
@@ -1092,7 +1111,6 @@ int pt_trace_hits(PtScene *s, size_t n, const float *ox, const float *oy, const 
     if (e == hipSuccess) e = hipMemcpy(hits + off, dh, k * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(PT_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
   }
-  (void)hipFree(buf);
   return rc;
 }
 

@@ -248,6 +248,31 @@ def test_flattened_scene_and_fast_tree_pass_the_host_check(name):
     # the two-triangle plane is a single leaf: no internal node, so no gate
     assert (0 if name == "plane" else 1) <= info["n_gates"] <= w.n_tris
     assert info["n_lights"] >= (0 if name == "plane" else 1)
+    # scenes that will not sit in LDS as a whole also get the eight-child form of the fast tree (children on an
+    # 8-bit grid, named by position), and pt_scene_check has verified it: every record reachable once, every box on
+    # the way to a leaf around its triangles with margin (or exactly flat); it cannot need more nodes than leaves
+    if name in ("plane", "box"):
+        assert info["n_oct_nodes"] == 0
+    else:
+        assert 0 < info["n_oct_nodes"] < info["n_fast_nodes"]
+        assert info["n_oct_nodes"] * 8 * 2 >= w.n_tris
+
+
+def test_eight_child_tree_is_left_out_where_it_cannot_be_exact(monkeypatch):
+    """Its boxes live on a grid, so it is built only when every box is finite and no triangle is ill-conditioned
+    (such a triangle is bounded by its gate alone, or by nothing): a soup with zero-area triangles keeps the
+    four-child tree only.  PT_OCT_ALWAYS builds it for a scene that fits LDS too, and the check still passes."""
+    rng = np.random.default_rng(5)
+    nt = 4000
+    v = rng.uniform(-1, 1, (nt, 1, 3)) + rng.normal(0, 0.05, (nt, 3, 3))
+    soup = [(np.ascontiguousarray(v.reshape(-1, 3), np.float32), np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3), 0)]
+    mats = [((0.5, 0.5, 0.5), (0, 0, 0))]
+    assert api.scene_check(O.World.from_meshes(soup, mats).export())["n_oct_nodes"] > 0
+    v[::9, 2] = v[::9, 1]                                   # two identical vertices: zero area
+    soup = [(np.ascontiguousarray(v.reshape(-1, 3), np.float32), np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3), 0)]
+    assert api.scene_check(O.World.from_meshes(soup, mats).export())["n_oct_nodes"] == 0
+    monkeypatch.setenv("PT_OCT_ALWAYS", "1")
+    assert api.scene_check(util.world("box").export())["n_oct_nodes"] > 0
 
 
 def test_fast_tree_keeps_ill_conditioned_triangles_reachable():

@@ -2,9 +2,13 @@
 closest-hit kernel (k_trace_queue, the plain instantiation without work counters), the HBM-side bytes,
 the L2 hit rate, the wave-level vector instructions, the share of LDS cycles lost to bank conflicts and
 the mean number of active lanes per vector instruction; plus fetch / write bytes of every kernel.
-FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte read requests of wide
-coalesced reads at 64 bytes, so it is doubled (checked against the bytes per ray this
-kernel reads from the ray queue when the scene itself sits in LDS).
+HBM-side read bytes come from the request counters of L2's memory side, sizes resolved: 32 bytes for every
+TCC_EA0_RDREQ_32B request, 128 bytes (one line) for every other TCC_EA0_RDREQ request.  That is what
+profiles/r03_fetch_calibration.txt measured on this chip for scattered 16-byte-per-lane gathers and for wide
+streaming reads alike: one request per missed line, none of them 32-byte, TCC_BUBBLE = 0, and FETCH_SIZE
+(which tallies 64 bytes per request on gfx950) exactly half of the bytes read.  Without the request counters
+the doubled FETCH_SIZE is used (the same number whenever no 32-byte request occurs).  Infinity-Cache hits are
+on the memory side of L2 and are counted.  WRITE_SIZE is in KiB and exact for 16-byte-per-lane stores.
 usage: pmc_to_traffic.py <pmc_summary.json> <config> [<pmc_lanes.json> [<spp of the counter runs>]] > profiles/pmc_<config>.json"""
 import json, sys
 
@@ -21,7 +25,14 @@ out = {"config": sys.argv[2], "source": sys.argv[1], "kernels": {}}
 for name, c in s.items():
     n = max(1, int(c["_dispatches"]))
     k = {"dispatches": n}
-    if "FETCH_SIZE" in c:
+    if "TCC_EA0_RDREQ_sum" in c:
+        n32 = c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        k["fetch_bytes_per_launch"] = (32.0 * n32 + 128.0 * (c["TCC_EA0_RDREQ_sum"] - n32)) / n
+        k["read_requests_per_launch"] = c["TCC_EA0_RDREQ_sum"] / n
+        k["read_requests_32B_per_launch"] = n32 / n
+        if "FETCH_SIZE" in c:
+            k["fetch_size_counter_bytes_per_launch"] = c["FETCH_SIZE"] * 1024.0 / n
+    elif "FETCH_SIZE" in c:
         k["fetch_bytes_per_launch"] = 2.0 * c["FETCH_SIZE"] * 1024.0 / n
     if "WRITE_SIZE" in c:
         k["write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024.0 / n
@@ -40,6 +51,8 @@ for name, c in s.items():
     if is_plain_trace(name):
         if "fetch_bytes_per_launch" in k and "write_bytes_per_launch" in k:
             out["trace_closest_hbm_bytes_per_launch"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+            out["hbm_bytes_how"] = ("reads: 128 B x TCC_EA0_RDREQ (32 B for the TCC_EA0_RDREQ_32B ones), writes: WRITE_SIZE"
+                                    if "read_requests_per_launch" in k else "reads: 2 x FETCH_SIZE, writes: WRITE_SIZE")
         for src, dst in (("l2_hit_rate", "trace_closest_l2_hit_rate"), ("valu_insts_per_launch", "trace_closest_valu_insts_per_launch"),
                          ("lds_conflict_frac", "trace_closest_lds_conflict_frac"), ("wait_any_frac", "trace_closest_wait_any_frac")):
             if src in k:

@@ -21,14 +21,15 @@ pass() {  # name, counters...
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum
+pass ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum
 pass sq SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
 pass sq2 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH SQ_INSTS_SMEM
 pass sq3 SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_sq $O/pmc_sq2 > $O/pmc_summary.json
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_ea $O/pmc_sq $O/pmc_sq2 > $O/pmc_summary.json
 python3 tools/pmc_summary.py $O/pmc_sq3 > $O/pmc_lanes.json
 USED_SPP=$(python3 -c "import json,re;print(int(re.search(r'(\d+) spp per GPU', json.loads(open('$O/bench_under_rocprof.json').read().strip().splitlines()[-1])['config']['workload']).group(1)))")
 python3 tools/pmc_to_traffic.py $O/pmc_summary.json $CFG $O/pmc_lanes.json $USED_SPP > $O/pmc_$CFG.json
 find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/trace -name "*kernel_trace.csv" -exec cp {} $O/kernel_trace.csv \;
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_sq $O/pmc_sq2 $O/pmc_sq3 $O/trace
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_ea $O/pmc_sq $O/pmc_sq2 $O/pmc_sq3 $O/trace
 echo done $CFG
