@@ -125,6 +125,7 @@ struct SceneDev {
   float margin;  // 2^-11 of the largest vertex coordinate plus 2e-5: how far outside a box counts as on it
   uint32_t quorum;      // lanes of a wave that must hold a parked leaf before triangles are tested (closest hit)
   uint32_t quorum_any;  // any-hit walks: the same in 64ths of the wave's unfinished lanes
+  uint32_t vertex_major; // split shading walks its visibility rays vertex by vertex (all lights of a vertex side by side), not light by light
   uint32_t refill;  // idle lanes of a wave at which k_trace_queue retires finished rays and fetches new ones
 };
 
@@ -679,6 +680,9 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
   }
 }
 
+#ifdef PT_DEBUG_ROUNDS
+__device__ unsigned long long g_dbg[16];
+#endif
 // The round of the eight-child tree (scenes outside LDS; pt_layout.h, Oct8Node).  A node names its children by
 // two base indices and a mask, so what waits on the stack is one entry of two words per node (first child, the
 // children still to visit) instead of a reference per child, and a step does no per-child bookkeeping: it tests
@@ -688,6 +692,17 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
 template <int MODE, bool ANY, bool COUNT, bool WANT_N>
 __device__ __forceinline__ void walk_round_oct(const SceneDev &S, const LdsScene &C, RayState &st, uint32_t stk,
                                                uint32_t stride, uint32_t &n_boxes, uint32_t &n_tris, uint32_t quorum) {
+#ifdef PT_DEBUG_ROUNDS
+  {
+    const unsigned long long mN = __ballot(st.live && (st.meta >> 16) == 0u), mB = __ballot(!st.done());
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&g_dbg[ANY ? 8 : 0], 1ull);
+      if (mN) atomicAdd(&g_dbg[(ANY ? 8 : 0) + 1], 1ull);
+      atomicAdd(&g_dbg[(ANY ? 8 : 0) + 2], (unsigned long long)__popcll(mN));
+      atomicAdd(&g_dbg[(ANY ? 8 : 0) + 3], (unsigned long long)__popcll(mB));
+    }
+  }
+#endif
   // a lane that holds two groups of parked leaves waits for the triangle tests before it reads another node
   if (st.live && (st.meta >> 16) == 0u) {
     const float far = (!ANY) ? st.cull : __builtin_inff();
@@ -780,6 +795,12 @@ __device__ __forceinline__ void walk_round_oct(const SceneDev &S, const LdsScene
   bool enough;
   if (ANY) enough = (uint32_t)__popcll(m_pend) * 64u >= S.quorum_any * (uint32_t)__popcll(__ballot(!st.done()));
   else enough = (uint32_t)__popcll(m_pend) >= quorum;
+#ifdef PT_DEBUG_ROUNDS
+  if ((enough || m_node == 0ull) && (threadIdx.x & 63) == 0) {
+    atomicAdd(&g_dbg[(ANY ? 8 : 0) + 4], 1ull);
+    atomicAdd(&g_dbg[(ANY ? 8 : 0) + 5], (unsigned long long)__popcll(m_pend));
+  }
+#endif
   if ((enough || m_node == 0ull) && st.pend != 0u) {
     // one leaf of the parked group: two triangle records (a leaf of one triangle is followed by a record no ray hits)
     const uint32_t k = (uint32_t)__builtin_ctz(st.pend);

@@ -486,7 +486,7 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
       return PT_OK;
     }
     // prepare the visibility rays, walk them (with per-lane refill when the scene is outside LDS), finish the vertices
-    if ((size_t)n * s->dev.n_lights > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
+    if (ShadowDev::items(n, s->dev.n_lights) > w.shadow_items) return fail(PT_ERR_DEVICE, "visibility-ray workspace too small");
     auto ka = k_shade<MODE, BLOCK, COUNT, false, 1, false>;
     hipLaunchKernelGGL(ka, grid_for(P, n), dim3(BLOCK), 0, st, D, P.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
                        w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
@@ -494,7 +494,7 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
     auto kw = P.resident ? k_shadow_walk<MODE, BLOCK, COUNT, true> : k_shadow_walk<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(kw, P.lds_bytes);
     if (rc != PT_OK) return rc;
-    const size_t items = (size_t)n * s->dev.n_lights;
+    const size_t items = (size_t)ShadowDev::items(n, s->dev.n_lights);
     hipLaunchKernelGGL(kw, grid_for(P, items), dim3(BLOCK), P.lds_bytes, st, D, P.lds,
                        run_length(P, items), n, w.hit, w.sd, s->acnt + 5, s->d_stats);
     HIP_TRY(hipGetLastError());
@@ -797,6 +797,8 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     if (q >= 1 && q <= 64) s->dev.quorum_any = (uint32_t)q;
   }
   s->dev.refill = 16;  // idle lanes at which a wave hands out new rays; measured on 7 M / 260 k triangles: 2 -> 2.82 / 5.38, 4 -> 2.96 / 5.71, 8 -> 3.08 / 5.98, 16 -> 3.13 / 6.11, 32 -> 3.07 / 5.98 G rays/s
+  s->dev.vertex_major = 1;
+  if (const char *e = std::getenv("PT_SHADOW_ORDER")) s->dev.vertex_major = std::strcmp(e, "light") != 0;  // measuring knob: "light" = light by light
   if (const char *e = std::getenv("PT_REFILL")) {  // tuning knob
     const int r = std::atoi(e);
     if (r >= 1 && r <= 64) s->dev.refill = (uint32_t)r;
@@ -1669,3 +1671,11 @@ int pt_resolve(const float *sum, size_t n, uint32_t spp, float *pixels) {
 }
 
 }  // extern "C"
+
+#ifdef PT_DEBUG_ROUNDS
+extern "C" int pt_debug_rounds(unsigned long long *out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_dbg), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
