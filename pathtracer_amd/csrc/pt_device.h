@@ -751,11 +751,20 @@ __device__ __forceinline__ void walk_round_oct(const SceneDev &S, const LdsScene
       const pt_f2 t1x = __builtin_elementwise_fma(pair2((float)((fxw[w] >> s0) & 0xffu), (float)((fxw[w] >> s1) & 0xffu)), splat2(ax), splat2(bfx));
       const pt_f2 t1y = __builtin_elementwise_fma(pair2((float)((fyw[w] >> s0) & 0xffu), (float)((fyw[w] >> s1) & 0xffu)), splat2(ay), splat2(bfy));
       const pt_f2 t1z = __builtin_elementwise_fma(pair2((float)((fzw[w] >> s0) & 0xffu), (float)((fzw[w] >> s1) & 0xffu)), splat2(az), splat2(bfz));
-      // NaN (an infinite 1/d against a plane it cannot order) never restricts
-      const float na = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x.x), t0y.x), t0z.x), fa = fminf(fminf(fminf(far, t1x.x), t1y.x), t1z.x);
-      const float nb = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x.y), t0y.y), t0z.y), fb = fminf(fminf(fminf(far, t1x.y), t1y.y), t1z.y);
-      hm |= (fa >= na) ? (1u << k) : 0u;
-      hm |= (fb >= nb) ? (2u << k) : 0u;
+      // NaN (an infinite 1/d against a plane it cannot order) never restricts.  A visibility walk has no far limit:
+      // it leaves the infinity out of the minimum and asks "not nearer than the entry" instead, which accepts the
+      // all-NaN case as the infinity did.
+      const float na = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x.x), t0y.x), t0z.x);
+      const float nb = fmaxf(fmaxf(fmaxf(S.tmin_own, t0x.y), t0y.y), t0z.y);
+      if (ANY) {
+        const float fa = fminf(fminf(t1x.x, t1y.x), t1z.x), fb = fminf(fminf(t1x.y, t1y.y), t1z.y);
+        hm |= !(fa < na) ? (1u << k) : 0u;
+        hm |= !(fb < nb) ? (2u << k) : 0u;
+      } else {
+        const float fa = fminf(fminf(fminf(far, t1x.x), t1y.x), t1z.x), fb = fminf(fminf(fminf(far, t1x.y), t1y.y), t1z.y);
+        hm |= (fa >= na) ? (1u << k) : 0u;
+        hm |= (fb >= nb) ? (2u << k) : 0u;
+      }
     }
     const uint32_t cbase = __float_as_uint(p1.x), tbase = __float_as_uint(p1.y), masks = __float_as_uint(p1.z);
     const uint32_t imask = masks & 0xffu, lall = (masks >> 8) & 0xffu;   // internal children; leaf children
