@@ -1499,7 +1499,11 @@ int pt_render_multi(PtScene *const *scenes, int n, const PtCamera *cam, int W, i
       }
     devices.push_back(scenes[g]->device);
   }
-  if (n == 1) return pt_render(scenes[0], cam, W, H, spp_begin, spp_count, seed, opt, accum, counters);
+  // PT_MULTI_FORCE_RCCL=1 (the other rehearsal switch): a single scene takes the general path too, so that a box
+  // with one GPU executes the library loading, the communicator and the grouped all-reduce (over one rank).
+  const char *force_env = std::getenv("PT_MULTI_FORCE_RCCL");
+  const bool force_rccl = force_env && std::atoi(force_env) != 0;
+  if (n == 1 && !force_rccl) return pt_render(scenes[0], cam, W, H, spp_begin, spp_count, seed, opt, accum, counters);
   PtOptions o;
   if (opt) o = *opt; else pt_options_default(&o);
   const uint32_t stride = o.spp_stride ? o.spp_stride : 1;

@@ -234,6 +234,22 @@ def test_render_multi_rehearsed_on_one_device(api, monkeypatch):
         s.close()
 
 
+def test_render_multi_all_reduce_runs_through_rccl(api, monkeypatch):
+    """The RCCL part of pt_render_multi on a box with one GPU: with PT_MULTI_FORCE_RCCL=1 a single scene takes the
+    general path, so librccl is loaded by name, a communicator is made for the device list and the grouped
+    all-reduce runs (over one rank: the sum of one accumulator is that accumulator, bit for bit).  Twice, so that
+    the second call finds the communicator the first one made."""
+    import torch  # noqa: F401  (a process that already holds an RCCL shares it)
+    ds = api.DeviceScene(util.world("atrium_small").export())
+    cam = api.make_camera(vw=16, vh=9)
+    a, ca = ds.render(cam, 160, 90, 6, seed=6)
+    monkeypatch.setenv("PT_MULTI_FORCE_RCCL", "1")
+    for _ in range(2):
+        b, cb = api.render_multi([ds], cam, 160, 90, 6, seed=6)
+        assert (util.bits(a) == util.bits(b)).all() and ca.as_dict() == cb.as_dict()
+    ds.close()
+
+
 def test_render_multi_over_all_devices(api):
     """The samples dealt over every visible device and merged by one RCCL all-reduce: the frame one device
     renders, up to the order of the float additions; ray counts add up exactly."""
