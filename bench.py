@@ -262,7 +262,7 @@ def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, 
     def step(n_spp):
         accum.zero_()
         c = ds.render_dev(cam, W, H, n_spp, accum.data_ptr(), spp_begin=rank, seed=0, opt=opt, stream=stream)
-        if world > 1:
+        if dist.is_initialized():
             dist.all_reduce(accum)
         return c
 
@@ -281,7 +281,7 @@ def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, 
     torch.cuda.synchronize()
     ds.profile(not args.no_profile)
     ds.read_profile()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -289,7 +289,7 @@ def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, 
     for _ in range(steps):
         last = step(spp)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -298,7 +298,7 @@ def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, 
 
     rays = last.rays_closest + last.rays_shadow
     tot = torch.tensor([dt, float(rays), float(last.paths), 1.0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -345,6 +345,20 @@ def config_line(name, cfg, r, cpu):
     return line
 
 
+def claim_stdout():
+    """Keeps stdout for the one JSON line: everything else a run writes there (RCCL prints a version banner to
+    stdout when a communicator is made) goes to stderr.  Returns the descriptor to hand to emit()."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
+
+
+def emit(fd, obj):
+    sys.stdout.flush()
+    os.write(fd, (json.dumps(obj) + "\n").encode())
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -376,6 +390,7 @@ def run_inprocess(args):
     library's own RCCL all-reduce).  The timed region is the whole call, host accumulator included."""
     import numpy as np
     from pathtracer_amd import api, host
+    out_fd = claim_stdout()
     n = args.gpus
     if args.share_device:
         os.environ["PT_MULTI_SHARE_DEVICE"] = "1"
@@ -417,7 +432,7 @@ def run_inprocess(args):
                    "multi": "inprocess", "share_device": bool(args.share_device)},
         "samples_per_s": c.paths * K / dt, "finite": bool(np.isfinite(acc).all()), "ranks_seen": n,
     }
-    print(json.dumps(out), flush=True)
+    emit(out_fd, out)
 
 
 def main():
@@ -436,11 +451,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    out_fd = claim_stdout()
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group is made even for one rank, so that a one-GPU box
+    # runs the same RCCL calls (group of one) as a node does
+    if world_env is not None:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -483,8 +501,8 @@ def main():
             lines.append(config_line(other, c, r, cpu))
         out["configs"] = lines
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit(out_fd, out)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
