@@ -278,6 +278,31 @@ __device__ __forceinline__ uint32_t pop_ref(const LdsScene &C, uint32_t stk, uin
   return C.spill[(size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride];
 }
 
+// The eight-child walk stacks two words per node, always together: in LDS they lie side by side (entry pair
+// sp/2 of lane t at word base + sp*stride + 2*t, where the one-word form has entries sp and sp + 1 of lanes t and
+// t + ...), written and read as one 64-bit access.  sp and C.stack_lds are even.
+typedef unsigned long long __attribute__((address_space(3))) *pt_lds_u64;
+__device__ __forceinline__ void push_pair(const LdsScene &C, uint32_t stk, uint32_t stride, int sp, uint32_t a, uint32_t b) {
+  if ((uint32_t)sp < C.stack_lds) {
+    *(pt_lds_u64)((pt_lds_u32)pt_smem + (stk + threadIdx.x + (uint32_t)sp * stride)) = ((unsigned long long)b << 32) | a;
+  } else {
+    uint32_t *q = C.spill + (size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride;
+    q[0] = a;
+    q[C.spill_stride] = b;
+  }
+}
+__device__ __forceinline__ void pop_pair(const LdsScene &C, uint32_t stk, uint32_t stride, int sp, uint32_t &a, uint32_t &b) {
+  if ((uint32_t)sp < C.stack_lds) {
+    const unsigned long long v = *(pt_lds_u64)((pt_lds_u32)pt_smem + (stk + threadIdx.x + (uint32_t)sp * stride));
+    a = (uint32_t)v;
+    b = (uint32_t)(v >> 32);
+  } else {
+    const uint32_t *q = C.spill + (size_t)((uint32_t)sp - C.stack_lds) * C.spill_stride;
+    a = q[0];
+    b = q[C.spill_stride];
+  }
+}
+
 // Walks the tree for one ray per lane.  MODE: PT_TRACE_EXACT reaches exactly the leaves the
 // reference reaches; PT_TRACE_FAST additionally skips leaves and groups whose box
 // the ray misses (with slack) and subtrees that start beyond the best hit (with
@@ -777,8 +802,8 @@ __device__ __forceinline__ void walk_round_oct(const SceneDev &S, const LdsScene
     }
     if (hn != 0u) {
       if ((st.gw & 0xffu) != 0u) {  // the siblings still to visit wait on the stack
-        push_ref(C, stk, stride, st.sp, st.gbase); ++st.sp;
-        push_ref(C, stk, stride, st.sp, st.gw); ++st.sp;
+        push_pair(C, stk, stride, st.sp, st.gbase, st.gw);
+        st.sp += 2;
       }
       st.gbase = cbase;
       st.gw = (desc << 16) | (imask << 8) | hn;
@@ -787,8 +812,8 @@ __device__ __forceinline__ void walk_round_oct(const SceneDev &S, const LdsScene
       if (st.sp == 0) {
         st.live = false;
       } else {
-        --st.sp; st.gw = pop_ref(C, stk, stride, st.sp);
-        --st.sp; st.gbase = pop_ref(C, stk, stride, st.sp);
+        st.sp -= 2;
+        pop_pair(C, stk, stride, st.sp, st.gbase, st.gw);
       }
     }
     if (st.live) {

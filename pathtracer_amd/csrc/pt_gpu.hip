@@ -226,6 +226,7 @@ static int make_plan(PtScene *s, int kind) {
     const int st = std::atoi(e);
     if (st >= 4 && st <= 128 && (size_t)st * p.block * 4 <= 128 * 1024) p.stack = st;
   }
+  if (oct) p.stack &= ~1;  // its entries are pairs of words (push_pair)
   const size_t node_bytes = (size_t)n_nodes * node_lds;
   const size_t tri_bytes = (size_t)n_tris * sizeof(ptl::TriRec);
   // lays the LDS of a workgroup out for p.block threads with at most `share` bytes of the CU's LDS
