@@ -368,6 +368,12 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
         }
         pool = pool_end - pool > n_idle ? pool + n_idle : pool_end;
         const unsigned long long m_now = __ballot(busy);
+#ifdef PT_DEBUG_ROUNDS
+        if ((threadIdx.x & 63) == 0) {
+          atomicAdd(&ptd::g_dbg[(ANY ? 8 : 0) + 6], 1ull);
+          atomicAdd(&ptd::g_dbg[(ANY ? 8 : 0) + 7], (unsigned long long)__popcll(m_now & ~m_busy));
+        }
+#endif
         if (m_now == 0) {
           if (!more && pool >= pool_end) break;
           continue;  // nothing to walk among these items, or the run is used up: fetch again

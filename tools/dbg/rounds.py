@@ -10,7 +10,8 @@ bench.main()
 out = (C.c_ulonglong * 16)()
 assert api.lib().pt_debug_rounds(out) == 0
 for k, tag in ((0, 'closest'), (8, 'visibility')):
-    r, rn, ln, lb, rl, ll = [out[k + i] for i in range(6)]
+    r, rn, ln, lb, rl, ll, ev, evl = [out[k + i] for i in range(8)]
     if r == 0: continue
     print('%s %s: rounds %d; node part ran in %.2f of them with %.1f lanes (of %.1f lanes that hold a ray); leaf part ran in %.2f with %.1f lanes'
           % (name, tag, r, rn / r, ln / max(1, rn), lb / r, rl / r, ll / max(1, rl)))
+    print('   refill events %d (one per %.1f rounds), %.1f rays handed out per event' % (ev, r / max(1, ev), evl / max(1, ev)))
