@@ -226,6 +226,56 @@ def roofline_block(name, mode, spp, info, prof, counts, count_spp):
     return roof
 
 
+def visibility_block(name, spp, info, prof, counts):
+    """The same figures for k_shadow_walk, the visibility walk of split shading (scenes outside LDS; a scene in
+    LDS walks its visibility rays inside the shading kernel).  Algorithmic bytes per ray: 29 B of stream (hit
+    point 12 B, direction 12 B, the vertex's t 4 B in, the answer 1 B out) + 10 B per child box of the
+    eight-child tree (28 B in the four-child tree) + 36 B per triangle tested."""
+    launches = int(prof.get("visibility_launches", 0))
+    if launches <= 0 or prof.get("visibility_ms", 0) <= 0 or not prof.get("visibility_rays"):
+        return None
+    avg_ms = prof["visibility_ms"] / launches
+    pmc = load_pmc(name)
+    if pmc.get("spp") not in (None, spp):
+        pmc = {}
+    traffic = pmc.get("visibility_hbm_bytes_per_launch")
+    roof = {
+        "bound": "hbm", "kernel": "k_shadow_walk (visibility)",
+        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
+        "avg_launch_ms": avg_ms, "launches": launches, "total_ms": prof["visibility_ms"],
+        "rays_per_launch": prof["visibility_rays"] / launches,
+        "l2_hit_rate": pmc.get("visibility_l2_hit_rate"),
+        "profile": "profiles/pmc_%s.json" % name if pmc else None,
+    }
+    if traffic:
+        roof["hbm_side"] = {"bytes_per_launch": traffic, "GB_per_s": traffic / (avg_ms * 1e-3) / 1e9,
+                            "frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "how": pmc.get("hbm_bytes_how")}
+    if counts is not None and counts.rays_shadow:
+        box_bytes = 10.0 if info.get("n_oct_nodes", 0) > 0 else 28.0
+        per_ray = (box_bytes * counts.shadow_node_boxes + 36.0 * counts.shadow_tri_tests) / counts.rays_shadow + 29.0
+        roof["node_boxes_per_ray"] = counts.shadow_node_boxes / counts.rays_shadow
+        roof["tri_tests_per_ray"] = counts.shadow_tri_tests / counts.rays_shadow
+        roof["algorithmic_bytes_per_ray"] = per_ray
+        roof["achieved"] = per_ray * roof["rays_per_launch"] / (avg_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+    valu = pmc.get("visibility_valu_insts_per_launch")
+    if valu:
+        rate = valu / (avg_ms * 1e-3) / 1e9
+        roof["valu_issue"] = {
+            "achieved": rate, "unit": "G wave-instr/s",
+            "peak_datasheet": VALU_PEAK_DATASHEET_GINST, "frac_datasheet": rate / VALU_PEAK_DATASHEET_GINST,
+            "sustained_under_load": VALU_SUSTAINED_GINST,
+            "active_lanes_of_64": pmc.get("visibility_active_lanes"),
+            "lds_bank_conflict_frac": pmc.get("visibility_lds_conflict_frac"),
+            "wave_time_waiting_on_memory": pmc.get("visibility_wait_any_frac"),
+        }
+    roof["binding_bound"] = "scattered_gather_rate (L1/L2 requests per second) and vector-instruction issue, not HBM bytes"
+    if roof.get("frac") is not None:
+        roof["note"] = ("the scene is served by L2 and the Infinity Cache as well as HBM, so the algorithmic bytes per "
+                        "second may exceed the HBM peak; hbm_side is what crossed the memory side of L2")
+    return roof
+
+
 def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, local_rank, world, dev):
     """Builds the scene, renders `warmup` untimed and `steps` timed frames of it and returns the
     measurements (on every rank; sums and the slowest rank's time are already reduced)."""
@@ -325,7 +375,18 @@ def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, 
         "roofline": None,
     }
     if not args.no_profile:
-        res["roofline"] = roofline_block(name, mode, spp, info, prof, counts, count_spp)
+        # `roofline` is the block of the kernel the frame spends most of its time in: the closest-hit walk, or
+        # for a scene with many lights the visibility walk; the other one rides along
+        closest = roofline_block(name, mode, spp, info, prof, counts, count_spp)
+        vis = visibility_block(name, spp, info, prof, counts)
+        if closest is not None:
+            closest["total_ms"] = prof["trace_ms"]
+        if vis is not None and closest is not None and vis["total_ms"] > closest["total_ms"]:
+            res["roofline"], res["roofline_closest_hit"] = vis, closest
+        else:
+            res["roofline"] = closest
+            if vis is not None:
+                res["roofline_visibility"] = vis
     ds.close()
     scene.close()
     return res, (meshes, mats, cam_kw, {k: v for k, v in opt_kw.items() if k not in ("trace_mode", "batch_spp")})
@@ -340,6 +401,9 @@ def config_line(name, cfg, r, cpu):
         "kernel_ms_per_step": r["kernel_ms_per_step"], "finite": r["finite"],
         "roofline": r["roofline"],
     }
+    for k in ("roofline_visibility", "roofline_closest_hit"):
+        if r.get(k) is not None:
+            line[k] = r[k]
     if cpu is not None:
         line["cpu_baseline"] = cpu
     return line
@@ -483,6 +547,9 @@ def main():
     }
     if res["roofline"] is not None:
         out["roofline"] = res["roofline"]
+    for k in ("roofline_visibility", "roofline_closest_hit"):
+        if res.get(k) is not None:
+            out[k] = res[k]
     do_cpu = world == 1 and rank == 0 and not args.no_cpu
     if do_cpu:
         out["cpu_baseline"] = cpu_baseline(meshes, mats, cfg, cam_kw, opt_kw)

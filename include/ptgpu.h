@@ -185,6 +185,9 @@ typedef struct PtProfile {
   double tail_ms;         /* the kernel that follows the last paths of a batch to their ends */
   uint64_t tail_launches;
   uint64_t trace_rays;    /* rays walked by the closest-hit kernel's launches (the tail kernel's are not among them) */
+  double visibility_ms;   /* the visibility-walk kernel of split shading (part of shade_ms; 0 for a scene in on-chip memory, whose shading kernel walks in place) */
+  uint64_t visibility_launches;
+  uint64_t visibility_rays; /* visibility rays those launches walked */
 } PtProfile;
 
 const char *pt_last_error(void);

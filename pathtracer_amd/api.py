@@ -68,7 +68,8 @@ class PtCounters(C.Structure):
 class PtProfile(C.Structure):
     _fields_ = [("trace_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double),
                 ("trace_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("tail_ms", C.c_double),
-                ("tail_launches", C.c_uint64), ("trace_rays", C.c_uint64)]
+                ("tail_launches", C.c_uint64), ("trace_rays", C.c_uint64), ("visibility_ms", C.c_double),
+                ("visibility_launches", C.c_uint64), ("visibility_rays", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("index_or_first", "<u4"), ("count", "<u4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3)])

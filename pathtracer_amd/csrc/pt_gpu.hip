@@ -124,7 +124,7 @@ struct PtScene {
   bool short_rays = false;                 // the rays of the next launches all have |d| <= 2 (SceneDev::tmin_own)
   uint32_t tail_paths = 0;                 // PT_TAIL: a batch with at most this many live paths is finished by k_tail (0: never)
   bool tail_given = false;                 // PT_TAIL was set; otherwise tail_limit() chooses
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 4, 5: around the visibility walk of split shading
   PtProfile prof{};
   // What the launches of the call in progress use: the scene's own workspace and counter block, or
   // (pt_render_dev_static) pieces of the library's static device buffer.
@@ -496,9 +496,11 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
     int rc = allow_lds(kw, P.lds_bytes);
     if (rc != PT_OK) return rc;
     const size_t items = (size_t)ShadowDev::items(n, s->dev.n_lights);
+    if (s->profile) HIP_TRY(hipEventRecord(s->ev[4], st));
     hipLaunchKernelGGL(kw, grid_for(P, items), dim3(BLOCK), P.lds_bytes, st, D, P.lds,
                        run_length(P, items), n, w.hit, w.sd, s->acnt + 5, s->d_stats);
     HIP_TRY(hipGetLastError());
+    if (s->profile) HIP_TRY(hipEventRecord(s->ev[5], st));
     auto kb = s->dev.n_tex != 0 ? k_shade<MODE, BLOCK, COUNT, false, 2, true> : k_shade<MODE, BLOCK, COUNT, false, 2, false>;
     hipLaunchKernelGGL(kb, grid_for(P, n), dim3(BLOCK), 0, st, D, P.lds, kRun, F, depth, n, in, w.hit, out, w.sd,
                        w.chunk_mask, w.chunk_base, w.block_tot, s->acnt, w.rad, s->d_stats);
@@ -732,7 +734,7 @@ void pt_scene_free(PtScene *s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->h_cnt) (void)hipHostFree(s->h_cnt);
   if (s->h_stats) (void)hipHostFree(s->h_stats);
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 6; ++k)
     if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
   if (s->ev_last) (void)hipEventDestroy(s->ev_last);
   delete s;
@@ -982,7 +984,7 @@ int pt_scene_profile(PtScene *s, int enable) {
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(s->device));
   if (enable)
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 6; ++k)
       if (!s->ev[k]) HIP_TRY(hipEventCreate(&s->ev[k]));
   s->profile = enable != 0;
   return PT_OK;
@@ -1221,6 +1223,11 @@ static int render_batches(PtScene *s, FrameDev &F, const PtOptions &o, uint32_t 
         s->prof.trace_launches += 1;
         s->prof.shade_launches += 1;
         s->prof.trace_rays += n;
+        if (plan_of(s, o.trace_mode).split) {
+          if ((rc = elapsed(4, 5, s->prof.visibility_ms)) != PT_OK) return rc;
+          s->prof.visibility_launches += 1;
+          s->prof.visibility_rays += (uint64_t)s->h_cnt[1] * s->dev.n_lights;
+        }
       }
       cur ^= 1;
       c.rays_closest += n;

@@ -574,7 +574,10 @@ __global__ __launch_bounds__(BLOCK) void k_hits_api(SceneDev S, LdsPlan plan, ui
 // by light, so that the shading phases (one vertex per lane, one light after the other) read and write whole
 // lines.  k_shadow_walk hands the rays out vertex by vertex (walk item j = i*L + l): the rays of one vertex leave
 // from one point and reach their leaves together, which keeps more lanes in step than neighbouring vertices'
-// rays towards one light do (1 M triangles, 64 lights: 6.96 -> 7.60 G rays/s; one light: the same order).
+// rays towards one light do (1 M triangles, 64 lights: 6.96 -> 8.4 G rays/s at 4 samples per pixel; one light: the
+// same order).  Its fetch gathers a vertex's directions from L lines that the chunk's other vertices share;
+// transposing them in the shading phase (an LDS tile per wave, a vertex's directions side by side) was measured
+// slower: 32-byte pieces written per vertex cost that phase more than the walk gains.
 struct ShadowDev {
   float *vbase;            // per vertex: hit point x, y, z; arrays vstride floats apart
   uint32_t vstride;
@@ -592,6 +595,9 @@ struct ShadowDev {
   __device__ __forceinline__ float *wz() const { return ibase + 5 * istride; }
   __device__ __forceinline__ uint8_t *vis() const { return vis_; }
   __device__ __forceinline__ static size_t at(uint32_t i, uint32_t l, uint32_t L) { return ((size_t)(i >> 6) * L + l) * 64u + (i & 63u); }
+  // the answers, one byte each, vertex by vertex: the walk stores them one lane at a time, and a vertex's bytes
+  // side by side merge in L2 (light by light they went out as a 32-byte sector per byte)
+  __device__ __forceinline__ static size_t vis_at(uint32_t i, uint32_t l, uint32_t L) { return (size_t)i * L + l; }
   // rays to walk for n vertices: whole chunks
   __host__ __device__ __forceinline__ static uint64_t items(uint32_t n, uint32_t L) { return (uint64_t)((n + 63u) & ~63u) * L; }
 };
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256) ? PT_SHADOW_OCC : 1) 
         }
         if (i >= n || hit.t(i) == __builtin_inff()) return false;  // no vertex, no light loop: nobody reads vis[k]
         const size_t k = ShadowDev::at(i, l, L);
-        j = k;
+        j = ShadowDev::vis_at(i, l, L);  // where retire puts the answer
         o = mk(sd.x()[i], sd.y()[i], sd.z()[i]);
         d = mk(sd.tx()[k], sd.ty()[k], sd.tz()[k]);
         return true;
@@ -852,7 +858,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(SceneDev S, LdsPlan plan, uint3
               local = add(local, w);
             } else {
               const size_t k = ShadowDev::at(i, l, S.n_lights);
-              if (!sd.vis()[k]) continue;
+              if (!sd.vis()[ShadowDev::vis_at(i, l, S.n_lights)]) continue;
               local = add(local, mk(sd.wx()[k], sd.wy()[k], sd.wz()[k]));
             }
           }

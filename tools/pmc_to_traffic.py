@@ -13,11 +13,15 @@ usage: pmc_to_traffic.py <pmc_summary.json> <config> [<pmc_lanes.json> [<spp of 
 import json, sys
 
 
-def is_plain_trace(name):
-    if "k_trace_queue<" not in name:
+def is_plain(name, kernel):
+    if kernel + "<" not in name:
         return False
     args = name.split("<", 1)[1].split(">")[0].split(",")
     return len(args) >= 3 and args[2].strip() == "false"   # MODE, BLOCK, COUNT, ...
+
+
+def is_plain_trace(name):
+    return is_plain(name, "k_trace_queue")
 
 
 s = json.load(open(sys.argv[1]))
@@ -57,10 +61,18 @@ for name, c in s.items():
                          ("lds_conflict_frac", "trace_closest_lds_conflict_frac"), ("wait_any_frac", "trace_closest_wait_any_frac")):
             if src in k:
                 out[dst] = k[src]
+    if is_plain(name, "k_shadow_walk"):  # the visibility walk of split shading, the same figures
+        if "fetch_bytes_per_launch" in k and "write_bytes_per_launch" in k:
+            out["visibility_hbm_bytes_per_launch"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+        for src in ("l2_hit_rate", "valu_insts_per_launch", "lds_conflict_frac", "wait_any_frac"):
+            if src in k:
+                out["visibility_" + src] = k[src]
 if len(sys.argv) > 3:
     for name, c in json.load(open(sys.argv[3])).items():
         if is_plain_trace(name) and c.get("SQ_ACTIVE_INST_VALU"):
             out["trace_closest_active_lanes"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
+        if is_plain(name, "k_shadow_walk") and c.get("SQ_ACTIVE_INST_VALU"):
+            out["visibility_active_lanes"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
 if len(sys.argv) > 4:
     out["spp"] = int(sys.argv[4])  # bench.py applies per-launch figures only to runs of the same sample count
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
