@@ -284,6 +284,8 @@ def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, 
     from pathtracer_amd import api, host, distributed
 
     W, H = cfg["W"], cfg["H"]
+    if rank == 0:  # a line per configuration on stderr: a long run shows that it is alive
+        print("[bench] %s: building the scene" % name, file=sys.stderr, flush=True)
     if world > 1:
         if scaling == "strong":
             _, spp, _ = distributed.shard(spp_total, rank, world)     # rank r renders indices r, r + world, ...
@@ -329,6 +331,8 @@ def run_config(name, cfg, spp_total, scaling, args, steps, warmup, count, rank, 
     for _ in range(warmup):
         step(spp)
     torch.cuda.synchronize()
+    if rank == 0:
+        print("[bench] %s: %d timed frame(s) of %d spp" % (name, steps, spp), file=sys.stderr, flush=True)
     ds.profile(not args.no_profile)
     ds.read_profile()
     if dist.is_initialized():

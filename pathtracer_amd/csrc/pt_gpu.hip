@@ -802,6 +802,10 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   s->dev.refill = 16;  // idle lanes at which a wave hands out new rays; measured on 7 M / 260 k triangles: 2 -> 2.82 / 5.38, 4 -> 2.96 / 5.71, 8 -> 3.08 / 5.98, 16 -> 3.13 / 6.11, 32 -> 3.07 / 5.98 G rays/s
   s->dev.vertex_major = 1;
   if (const char *e = std::getenv("PT_SHADOW_ORDER")) s->dev.vertex_major = std::strcmp(e, "light") != 0;  // measuring knob: "light" = light by light
+  if (const char *e = std::getenv("PT_SHADOW_GROUP")) {  // measuring knob: wave fills of 64/g vertices x g lights
+    const int g = std::atoi(e);
+    if (g >= 2 && g < 64 && 64 % g == 0 && s->dev.n_lights % (uint32_t)g == 0) s->dev.vertex_major = (uint32_t)g;
+  }
   if (const char *e = std::getenv("PT_REFILL")) {  // tuning knob
     const int r = std::atoi(e);
     if (r >= 1 && r <= 64) s->dev.refill = (uint32_t)r;

@@ -617,7 +617,16 @@ __global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256) ? PT_SHADOW_OCC : 1) 
       [&](uint64_t &j, V3 &o, V3 &d) {
         const uint32_t L = S.n_lights;
         uint32_t i, l;
-        if (S.vertex_major) {
+        if (S.vertex_major >= 2u) {
+          // measuring knob: wave fills of (64/g vertices) x (g lights), g = S.vertex_major dividing 64 and L
+          const uint32_t g = S.vertex_major, vb = 64u / g;
+          const uint64_t per_blk = (uint64_t)vb * L;
+          const uint64_t blk = j / per_blk;
+          const uint32_t r = (uint32_t)(j - blk * per_blk);
+          const uint32_t lg = r / 64u, r2 = r % 64u;
+          i = (uint32_t)(blk * vb) + r2 / g;
+          l = lg * g + r2 % g;
+        } else if (S.vertex_major) {
           // j = i*L + l.  The lanes that fetch together hold consecutive items: the 64-bit division is done once
           // for the first of them, on the scalar unit, and a lane divides only its small distance from that item.
           const uint64_t j0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(j >> 32)) << 32) |
