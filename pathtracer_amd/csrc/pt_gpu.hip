@@ -666,6 +666,7 @@ static int make_frame(const PtCamera *cam, int W, int H, uint64_t seed, const Pt
   F.pdf_f = (float)(1 / (2 * M_PI) * o.rr_prob);  // camera.cpp:152, narrowed by operator/(vec, scalar)
   F.pi_f = (float)M_PI;
   F.dims_per_vertex = (3u * n_lights + 3u + 1u) & ~1u;
+  if (const char *e = std::getenv("PT_QUEUE_ORDER")) F.pixel_major = std::strcmp(e, "pixel") == 0;  // measuring knob
   return PT_OK;
 }
 

@@ -109,6 +109,7 @@ struct FrameDev {
   float pdf_f;           // (float)(1/(2*pi) * rr_prob), camera.cpp:152
   float pi_f;            // (float)M_PI, camera.cpp:122
   uint32_t dims_per_vertex;
+  uint32_t pixel_major;  // measuring knob: the batch's paths queued pixel by pixel (a pixel's samples side by side)
 };
 
 // What a traversal kernel keeps in LDS (see LdsScene) and how many words of the
@@ -182,13 +183,19 @@ __device__ __forceinline__ void camera_ray(const FrameDev &F, int px, int py, Pa
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameDev F, uint32_t n, QueueDev q) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const uint32_t s = i / F.P, p = i - s * F.P;
+  // a path's id is sample-in-batch * P + pixel whatever its place in the queue: radiance is written by id
+  uint32_t s = i / F.P, p = i - s * F.P;
+  if (F.pixel_major) {
+    const uint32_t sb = n / F.P;
+    p = i / sb;
+    s = i - p * sb;
+  }
   const int py = (int)(p / (uint32_t)F.W), px = (int)(p - (uint32_t)py * (uint32_t)F.W);
   PathRng rng;
   rng.init(F.seed, p, F.sample0 + s * F.stride);
   V3 o, d;
   camera_ray(F, px, py, rng, o, d);
-  q.store(i, o, d, mk(1.0f, 1.0f, 1.0f), mk(0.0f, 0.0f, 0.0f), i);
+  q.store(i, o, d, mk(1.0f, 1.0f, 1.0f), mk(0.0f, 0.0f, 0.0f), s * F.P + p);
 }
 
 // Camera::point_towards for every pixel, for callers that only want the directions.
