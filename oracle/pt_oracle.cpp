@@ -10,7 +10,7 @@
 // PARITY PINNING: the reference itself cannot be built in this environment
 // without stand-in headers (it needs <format>, <print>, std::unreachable and
 // the FFmpeg headers), so this restatement is pinned only by the known-answer
-// values the survey recorded from a run of the reference (closest-hit t bits
+// values recorded from an earlier run of the reference (closest-hit t bits
 // and barycentrics on examples/plane.obj, point_towards at the default camera);
 // everything those values do not cover is "parity unpinned".
 //

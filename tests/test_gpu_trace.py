@@ -95,7 +95,7 @@ def test_any_hit_matches_castray(api, name, mode):
 
 
 def test_known_answer_rays_plane(api):
-    """The rays whose reference results the survey recorded (t as bit patterns)."""
+    """The rays whose reference results were recorded from a run of the reference (t as bit patterns, tests/golden/plane_kat.json)."""
     ds = dev_scene(api, "plane")
     o = np.array([(1, 3, -1), (5.153648, 3, 0), (0, 0, 0), (0, 1e-6, 0), (0, 1.5e-6, 0), (0, 3, 0), (0, 3, 0),
                   (-6, 3, .5), (-1, 3, .5)], np.float32)
@@ -182,7 +182,7 @@ def test_hits_counter_matches_oracle(name, mode):
 
 
 def test_hits_counter_matches_the_reference_probe():
-    """The survey ran the reference on its 1 002-triangle room: hits of the primary rays that hit
+    """A recorded run of the reference on its 1 002-triangle room: hits of the primary rays that hit
     had mean 5.2 and maximum 7."""
     import json, os
     from pathtracer_amd import api

@@ -56,7 +56,7 @@ def test_plane_path_lengths():
 
 
 def test_bvh_depth_statistic_of_the_probe_scene():
-    """The survey's probe on its 1 002-triangle room reported HitData::hits (object.cpp:203,281-282)
+    """A recorded probe of the reference on its 1 002-triangle room reported HitData::hits (object.cpp:203,281-282)
     of mean 5.2, max 7 over 256x256 primary rays; the generator here follows that scene's description."""
     w = util.world("box")
     o, d = util.primary_rays(O.default_camera(), 256, 256)
