@@ -207,7 +207,7 @@ static int make_plan(PtScene *s, int kind) {
   // deeper trees keep only the first entries in LDS and spill the rest to global memory, so
   // that LDS still holds 16 waves per CU and a useful part of the tree
   int cap = wide ? 16 : 24;  // a descent of the four-child tree rarely holds more than a dozen entries
-  if (oct) cap = 24;         // two words per level of the eight-child tree
+  if (oct) cap = 16;         // two words per node with siblings left to visit: eight pairs, measured against 8 / 12 / 24 entries (more of the tree's top fits beside a shorter stack; at 8 the 7 M triangles spill too often)
   if (const char *e = std::getenv("PT_STACK_CAP")) {  // tuning knob
     const int c = std::atoi(e);
     if (c >= 4 && c <= 128) cap = c;
