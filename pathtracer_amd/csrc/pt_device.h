@@ -127,6 +127,8 @@ struct SceneDev {
   uint32_t quorum_any;  // any-hit walks: the same in 64ths of the wave's unfinished lanes
   uint32_t vertex_major; // split shading walks its visibility rays vertex by vertex (all lights of a vertex side by side), not light by light
   uint32_t refill;  // idle lanes of a wave at which k_trace_queue retires finished rays and fetches new ones
+  uint32_t refill_any;  // the same for visibility walks, whose hand-over is cheaper (a byte out, a ray in)
+  uint32_t cohort;      // visibility walks of a scene with many lights: a wave takes whole vertices (see k_shadow_walk)
 };
 
 struct HitRec {

@@ -495,7 +495,7 @@ static int launch_shade(PtScene *s, const PathFrame &F, int depth, uint32_t n, c
     auto kw = P.resident ? k_shadow_walk<MODE, BLOCK, COUNT, true> : k_shadow_walk<MODE, BLOCK, COUNT, false>;
     int rc = allow_lds(kw, P.lds_bytes);
     if (rc != PT_OK) return rc;
-    const size_t items = (size_t)ShadowDev::items(n, s->dev.n_lights);
+    const size_t items = (size_t)ShadowDev::walk_items(n, s->dev.n_lights, D.cohort != 0u);
     if (s->profile) HIP_TRY(hipEventRecord(s->ev[4], st));
     hipLaunchKernelGGL(kw, grid_for(P, items), dim3(BLOCK), P.lds_bytes, st, D, P.lds,
                        run_length(P, items), n, w.hit, w.sd, s->acnt + 5, s->d_stats);
@@ -811,6 +811,19 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
     const int r = std::atoi(e);
     if (r >= 1 && r <= 64) s->dev.refill = (uint32_t)r;
   }
+  s->dev.refill_any = s->dev.refill;
+  if (const char *e = std::getenv("PT_REFILL_ANY")) {  // tuning knob
+    const int r = std::atoi(e);
+    if (r >= 1 && r <= 64) s->dev.refill_any = (uint32_t)r;
+  }
+  // Visibility walks of a scene with many lights take whole vertices: a wave is filled with the rays of one
+  // vertex (or of a few) and hands out the next ones when all of them are done.  Rays from one point start in
+  // the same nodes and stay in step; a wave that mixes the rays of a vertex just begun with stragglers of
+  // earlier ones runs both of its steps, nodes and triangles, with part of its lanes (64 lights: 8.75 -> 9.30 G
+  // rays/s; one light, where 64 lanes are 64 different vertices: 7.3 -> 6.8 and 4.3 -> 3.2, so not there).
+  s->dev.cohort = s->dev.vertex_major == 1u && s->dev.n_lights >= 64u;
+  if (const char *e = std::getenv("PT_COHORT")) s->dev.cohort = s->dev.vertex_major == 1u && std::atoi(e) != 0;  // measuring knob
+  if (s->dev.cohort) s->dev.refill_any = 64;
   if (const char *e = std::getenv("PT_QUORUM")) {  // tuning knob
     const int q = std::atoi(e);
     if (q >= 1 && q <= 64) s->dev.quorum = (uint32_t)q;

@@ -346,7 +346,7 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
       const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
       const bool can_fetch = more || pool < pool_end;
       uint32_t n_idle_now = n_idle;
-      if ((n_idle >= S.refill && can_fetch) || m_busy == 0) {
+      if ((n_idle >= (ANY ? S.refill_any : S.refill) && can_fetch) || m_busy == 0) {
         if (!busy && mine != NONE) {
           retire(mine, st);
           mine = NONE;
@@ -605,8 +605,19 @@ struct ShadowDev {
   // the answers, one byte each, vertex by vertex: the walk stores them one lane at a time, and a vertex's bytes
   // side by side merge in L2 (light by light they went out as a 32-byte sector per byte)
   __device__ __forceinline__ static size_t vis_at(uint32_t i, uint32_t l, uint32_t L) { return (size_t)i * L + l; }
-  // rays to walk for n vertices: whole chunks
+  // (vertex, light) pairs the arrays hold for n vertices: whole chunks
   __host__ __device__ __forceinline__ static uint64_t items(uint32_t n, uint32_t L) { return (uint64_t)((n + 63u) & ~63u) * L; }
+  // work items of the walk.  In whole-vertex mode a wave's 64 lanes are filled with whole vertices only: 64/L
+  // vertices side by side (L <= 64, the lanes left over stay empty) or one vertex in ceil(L/64) fills.
+  __host__ __device__ __forceinline__ static uint64_t walk_items(uint32_t n, uint32_t L, bool whole) {
+    const uint64_t np = (n + 63u) & ~63u;
+    if (!whole || L == 0) return np * L;
+    if (L <= 64u) {
+      const uint32_t per_fill = 64u / L;
+      return (np + per_fill - 1u) / per_fill * 64u;
+    }
+    return np * ((L + 63u) / 64u) * 64u;
+  }
 };
 
 #ifndef PT_SHADOW_OCC
@@ -620,11 +631,32 @@ __global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256) ? PT_SHADOW_OCC : 1) 
   const LdsScene C = stage_scene<BLOCK, MODE>(S, plan, stk);
   uint32_t nb = 0, nt = 0;
   walk_items<MODE, true, COUNT, false, RES, !RES, BLOCK>(
-      S, C, stk, ShadowDev::items(n, S.n_lights), kRun, head, nb, nt,
+      S, C, stk, ShadowDev::walk_items(n, S.n_lights, S.cohort != 0u), kRun, head, nb, nt,
       [&](uint64_t &j, V3 &o, V3 &d) {
         const uint32_t L = S.n_lights;
         uint32_t i, l;
-        if (S.vertex_major >= 2u) {
+        if (L == 1u) {  // one light: item = vertex in every order
+          i = (uint32_t)j;
+          l = 0u;
+        } else if (S.cohort) {
+          // Whole vertices: the lanes that fetch together are one fill (the wave hands rays out only when all
+          // of its lanes are idle, and runs start at multiples of 64), fill f = j / 64 the same for all of them.
+          const uint32_t slot = (uint32_t)j & 63u;
+          const uint64_t f = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(j >> 38)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(j >> 6));
+          if (L <= 64u) {
+            const uint32_t per_fill = 64u / L, v = slot / L;
+            if (v >= per_fill) return false;
+            i = (uint32_t)(f * per_fill) + v;
+            l = slot - v * L;
+          } else {
+            const uint32_t fills = (L + 63u) / 64u;
+            const uint64_t v = f / fills;
+            i = (uint32_t)v;
+            l = (uint32_t)(f - v * fills) * 64u + slot;
+            if (l >= L) return false;
+          }
+        } else if (S.vertex_major >= 2u) {
           // measuring knob: wave fills of (64/g vertices) x (g lights), g = S.vertex_major dividing 64 and L
           const uint32_t g = S.vertex_major, vb = 64u / g;
           const uint64_t per_blk = (uint64_t)vb * L;
