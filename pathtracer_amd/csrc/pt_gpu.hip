@@ -821,7 +821,9 @@ static int upload(PtScene *s, const ptl::FlatScene &f) {
   // the same nodes and stay in step; a wave that mixes the rays of a vertex just begun with stragglers of
   // earlier ones runs both of its steps, nodes and triangles, with part of its lanes (64 lights: 8.75 -> 9.30 G
   // rays/s; one light, where 64 lanes are 64 different vertices: 7.3 -> 6.8 and 4.3 -> 3.2, so not there).
-  s->dev.cohort = s->dev.vertex_major == 1u && s->dev.n_lights >= 64u;
+  // Only where a vertex's rays fill whole waves: measured on the same terrain, 128 lights +6 %, but 8 / 16 / 32 /
+  // 48 / 96 lights (several vertices per wave, or lanes left empty) -11 / -15 / -6 / -10 / -10 %.
+  s->dev.cohort = s->dev.vertex_major == 1u && s->dev.n_lights >= 64u && s->dev.n_lights % 64u == 0u;
   if (const char *e = std::getenv("PT_COHORT")) s->dev.cohort = s->dev.vertex_major == 1u && std::atoi(e) != 0;  // measuring knob
   if (s->dev.cohort) s->dev.refill_any = 64;
   if (const char *e = std::getenv("PT_QUORUM")) {  // tuning knob
