@@ -17,7 +17,7 @@ for E in "PT_NO_RESIDENT=1" "PT_LEAF=8" "PT_LEAF=1" "PT_BLOCK=256" "PT_BLOCK=512
          "PT_LDS_SHARE=5" "PT_LDS_SHARE=7 PT_NO_RESIDENT=1" "PT_OCT_ALWAYS=1 PT_NO_RESIDENT=1 PT_TAIL=1000000000" \
          "PT_SHADOW_ORDER=light PT_NO_RESIDENT=1" "PT_SHADOW_ORDER=light PT_OCT_ALWAYS=1 PT_NO_RESIDENT=1" \
          "PT_OCT_ALWAYS=1 PT_NO_RESIDENT=1 PT_STACK=5" "PT_OCT_ALWAYS=1 PT_NO_RESIDENT=1 PT_STACK=6 PT_REFILL=1" \
-         "PT_SHADOW_GROUP=4 PT_NO_RESIDENT=1"; do
+         "PT_SHADOW_GROUP=4 PT_NO_RESIDENT=1" "PT_COHORT=1 PT_NO_RESIDENT=1" "PT_REFILL_ANY=3 PT_NO_RESIDENT=1"; do
   echo "== $E"
   env $E timeout -k 10 400 python3 -u -m pytest $TESTS -m gpu -x -q --timeout 120 --timeout-method thread \
       -k "not pipelines_agree and not stack_spill and not tail_kernel_and_wavefront" > gpurun_out/knob.log 2>&1
