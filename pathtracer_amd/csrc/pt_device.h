@@ -708,7 +708,7 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
 }
 
 #ifdef PT_DEBUG_ROUNDS
-__device__ unsigned long long g_dbg[16];
+__device__ unsigned long long g_dbg[24];
 #endif
 // The round of the eight-child tree (scenes outside LDS; pt_layout.h, Oct8Node).  A node names its children by
 // two base indices and a mask, so what waits on the stack is one entry of two words per node (first child, the

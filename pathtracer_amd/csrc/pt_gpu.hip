@@ -1706,8 +1706,8 @@ int pt_resolve(const float *sum, size_t n, uint32_t spp, float *pixels) {
 
 #ifdef PT_DEBUG_ROUNDS
 extern "C" int pt_debug_rounds(unsigned long long *out) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_dbg), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[24] = {0};
   return hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_dbg), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -341,6 +341,10 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
     st.pend = 0;
     st.meta = 0;
     st.gw = 0;
+#ifdef PT_DEBUG_ROUNDS
+    const unsigned long long dbg_t0 = wall_clock64();
+    unsigned long long dbg_te = 0;
+#endif
     for (;;) {
       const unsigned long long m_busy = __ballot(busy);
       const uint32_t n_idle = 64u - (uint32_t)__popcll(m_busy);
@@ -355,6 +359,9 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
           const uint32_t run = next_run(head, len);
           if ((uint64_t)run * 64u >= n) {
             more = false;
+#ifdef PT_DEBUG_ROUNDS
+            dbg_te = wall_clock64();
+#endif
           } else {
             pool = (uint64_t)run * 64u;
             const uint64_t e = ((uint64_t)run + len) * 64u;
@@ -382,7 +389,16 @@ __device__ __forceinline__ void walk_items(const SceneDev &S, const LdsScene &C,
         }
 #endif
         if (m_now == 0) {
-          if (!more && pool >= pool_end) break;
+          if (!more && pool >= pool_end) {
+#ifdef PT_DEBUG_ROUNDS
+            if ((threadIdx.x & 63) == 0) {  // wave time after the queue ran dry, and in all (100 MHz ticks)
+              const unsigned long long t1 = wall_clock64();
+              atomicAdd(&ptd::g_dbg[ANY ? 18 : 16], t1 - (dbg_te ? dbg_te : t1));
+              atomicAdd(&ptd::g_dbg[ANY ? 19 : 17], t1 - dbg_t0);
+            }
+#endif
+            break;
+          }
           continue;  // nothing to walk among these items, or the run is used up: fetch again
         }
         n_idle_now = 64u - (uint32_t)__popcll(m_now);
