@@ -303,6 +303,23 @@ def test_counters_and_profile(api):
     ds.close()
 
 
+def test_profile_times_the_visibility_walk_of_split_shading(api, monkeypatch):
+    """A scene outside on-chip memory shades in three kernels; the profile times the visibility walk on its own
+    and counts its rays (the tail kernel switched off so that the wavefront passes do all the work)."""
+    monkeypatch.setenv("PT_NO_RESIDENT", "1")
+    monkeypatch.setenv("PT_TAIL", "0")
+    ds = api.DeviceScene(util.world("terrain_small").export())
+    cam = api.make_camera(origin=(0, 0.5, 0), euler=(0.15, 0, 0), vw=16, vh=9)
+    ds.profile(True)
+    _, c = ds.render(cam, 96, 54, 2, seed=1)
+    p = ds.read_profile()
+    ds.profile(False)
+    ds.close()
+    assert p["visibility_launches"] == p["shade_launches"] >= 1
+    assert 0 < p["visibility_ms"] <= p["shade_ms"]
+    assert p["visibility_rays"] == c.rays_shadow > 0 and p["trace_rays"] == c.rays_closest
+
+
 def test_exact_and_fast_agree_on_a_full_render(api):
     """Fast traversal only skips work that cannot change the answer: on a full multi-bounce render
     (millions of rays that start on surfaces) the two modes give the same radiance sums bit for bit."""
