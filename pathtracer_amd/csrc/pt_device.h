@@ -556,11 +556,22 @@ __device__ __forceinline__ void walk_round(const SceneDev &S, const LdsScene &C,
       // S.tmin_own: these boxes are this tree's own, a triangle hit counts from t = 1e-6
       // (object.cpp:425), and a leaf box a margin thick can be left before the reference's EPSILON = 1e-5
       // by a ray with a long direction vector.
-      const float tn0 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.x), ay01.x), az01.x), tf0 = fminf(fminf(fminf(far, bx01.x), by01.x), bz01.x);
-      const float tn1 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.y), ay01.y), az01.y), tf1 = fminf(fminf(fminf(far, bx01.y), by01.y), bz01.y);
-      const float tn2 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.x), ay23.x), az23.x), tf2 = fminf(fminf(fminf(far, bx23.x), by23.x), bz23.x);
-      const float tn3 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.y), ay23.y), az23.y), tf3 = fminf(fminf(fminf(far, bx23.y), by23.y), bz23.y);
-      const bool h0 = tf0 >= tn0, h1 = tf1 >= tn1, h2 = tf2 >= tn2, h3 = tf3 >= tn3;
+      const float tn0 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.x), ay01.x), az01.x);
+      const float tn1 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax01.y), ay01.y), az01.y);
+      const float tn2 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.x), ay23.x), az23.x);
+      const float tn3 = fmaxf(fmaxf(fmaxf(S.tmin_own, ax23.y), ay23.y), az23.y);
+      bool h0, h1, h2, h3;
+      if (ANY) {
+        // no far limit: the infinity is left out of the minimum and the question is "not nearer than the entry",
+        // which accepts the all-NaN case as the infinity did
+        const float tf0 = fminf(fminf(bx01.x, by01.x), bz01.x), tf1 = fminf(fminf(bx01.y, by01.y), bz01.y);
+        const float tf2 = fminf(fminf(bx23.x, by23.x), bz23.x), tf3 = fminf(fminf(bx23.y, by23.y), bz23.y);
+        h0 = !(tf0 < tn0); h1 = !(tf1 < tn1); h2 = !(tf2 < tn2); h3 = !(tf3 < tn3);
+      } else {
+        const float tf0 = fminf(fminf(fminf(far, bx01.x), by01.x), bz01.x), tf1 = fminf(fminf(fminf(far, bx01.y), by01.y), bz01.y);
+        const float tf2 = fminf(fminf(fminf(far, bx23.x), by23.x), bz23.x), tf3 = fminf(fminf(fminf(far, bx23.y), by23.y), bz23.y);
+        h0 = tf0 >= tn0; h1 = tf1 >= tn1; h2 = tf2 >= tn2; h3 = tf3 >= tn3;
+      }
       if (h0 || h1 || h2 || h3) {
         // nearest child next; the others wait on the stack
         const float inf = __builtin_inff();
