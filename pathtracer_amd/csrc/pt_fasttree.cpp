@@ -58,7 +58,7 @@ struct FastBuilder {
 
   FastBuilder(const PtSceneDesc &dd, FlatScene &o) : d(dd), out(o) {}
 
-  static const int kBins = 16;
+  static const int kBins = 32;
 
   Box3 range_box(uint32_t lo, uint32_t hi) const {
     Box3 b;

@@ -611,7 +611,7 @@ static int effective_mode(const PtScene *s, int mode) {
   return mode;
 }
 // Origins up to this distance from the world origin (per coordinate) are inside the range of the pruning walks.
-static float near_limit(const PtScene *s) { return 16.0f * s->max_abs_coord; }
+static float near_limit(const PtScene *s) { return 8.0f * s->max_abs_coord; }
 // Largest |coordinate| among n origins on the host; NaN counts as beyond every limit.
 static bool host_origins_within(const float *ox, const float *oy, const float *oz, size_t n, float limit) {
   bool ok = true;
@@ -1303,7 +1303,7 @@ static int render_dev_impl(PtScene *s, const PtCamera *cam, int W, int H, uint32
   if (!valid_mode(o.trace_mode)) return fail(PT_ERR_INVALID, "unknown trace mode");
   o.trace_mode = effective_mode(s, o.trace_mode);
   if (o.trace_mode != PT_TRACE_EXACT && cam) {
-    // the margins of the pruning walks cover ray origins up to 16 times the scene's largest coordinate;
+    // the margins of the pruning walks cover ray origins up to 8 times the scene's largest coordinate;
     // every path of a frame starts at the camera (its later vertices lie on the scene)
     float far = 0;
     for (int k = 0; k < 3; ++k) far = std::fmax(far, std::fabs(cam->origin[k]));

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(BLOCK, (!RES && BLOCK == 256 && mode_wide(MODE) && 
 }
 
 // Which of a caller's rays a launch of the ray-query kernels walks.  The pruning walks are exact for origins
-// within `limit` of the world origin (16 times the scene's largest coordinate: their margins are relative to
+// within `limit` of the world origin (8 times the scene's largest coordinate: their margins are relative to
 // that coordinate, and the rounding error of a box test grows with the origin's distance), so a query in a
 // pruning mode is two launches: the pruning walk for the rays inside that range (SIDE_NEAR) and the exact walk
 // for the others (SIDE_FAR, which includes origins that are not finite).  A ray the launch leaves out costs it

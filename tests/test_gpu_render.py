@@ -304,7 +304,7 @@ def test_larger_frame_matches_oracle_bitwise(api, name, cam_kw):
 
 def test_camera_far_from_the_scene_still_matches_the_oracle(api):
     """A box test's rounding error grows with the distance of the ray's origin; the pruning walks carry a
-    margin for origins near the scene only, so a render whose camera stands farther away than 16 times the
+    margin for origins near the scene only, so a render whose camera stands farther away than 8 times the
     scene's largest coordinate runs the exact walk by itself.  Camera 5 000 units in front of the room's open
     side with a field of view that just frames it: radiance sums equal the oracle's."""
     kw = dict(origin=(0.0, 0.0, -5000.0), fov=0.06, vw=16, vh=9)

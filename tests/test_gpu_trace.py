@@ -362,7 +362,7 @@ def test_random_triangle_soups_bit_exact(api, seed):
 @pytest.mark.parametrize("name", ["box40", "atrium_small", "blob_small"])
 def test_origins_far_from_the_scene_match_in_every_mode(api, name):
     """The pruning walks carry margins for origins near the scene only (the rounding error of a box test grows
-    with the origin's distance).  The ray queries therefore walk every ray whose origin lies beyond 16 times the
+    with the origin's distance).  The ray queries therefore walk every ray whose origin lies beyond 8 times the
     scene's largest coordinate exactly, ray by ray, whatever mode was asked for: rays aimed at the scene from
     1 to 100 000 scene extents away, mixed in one call, equal Scene::castray in all three modes (closest hit,
     any hit and HitData::hits), through the host-pointer and the device-pointer entry points."""
@@ -455,3 +455,31 @@ def test_hit_with_a_nan_distance_is_never_recorded(api):
         assert not np.isnan(b["t"]).any() and b["tri"][0] >= 0      # the second ray leaves through the room's open side
     ds0.close()
     ds1.close()
+
+
+def test_garbage_hit_of_a_ray_in_a_triangles_plane_is_a_known_deviation(api):
+    """Known deviation of the pruning modes, pinned.  A ray that runs in the plane of a triangle to within rounding
+    (here: aimed at one of its vertices from far away, determinant -5e-9 where its rounding error is as large)
+    makes Triangle::intersect (object.cpp:406-429) compute u, v and t from noise; about one such ray in 10^7
+    lands inside the tests by accident and the reference reports a hit at a distance that has nothing to do with
+    where the triangle is (here t = 0.957 for a triangle the ray touches at t = 1.000, 1.2 units farther on; in
+    double precision the ray misses it: u = 1.9, v = 49).  The exact mode tests every triangle of every leaf the
+    ray passes, as the reference does, and returns that hit.  The pruning modes skip what begins beyond the best
+    hit they hold, and when the true closest hit (t = 0.9713) is found first the triangle's leaf, which begins at
+    t = 1, is never opened.  tools/dbg/near_limit.py measures the rate: 2 rays of 28 million aimed at vertices,
+    none among the rays of any other probe or test."""
+    w, ds = util.world("blob_small"), dev_scene(api, "blob_small")
+    o = np.array([[0xc1dd8081, 0xc0a3536a, 0x408aafef]], np.uint32).view(np.float32)
+    d = np.array([[0x41dddba3, 0x40d21d38, 0xbf96037e]], np.uint32).view(np.float32)
+    ref = w.castray(o, d)
+    assert ref["tri"][0] == 1395 and ref["t"][0] == np.float32(0.95703125) and ref["v"][0] == 0.0
+    exact = ds.trace_closest(o, d, api.PT_TRACE_EXACT)
+    assert exact["tri"][0] == 1395 and util.bits(exact["t"])[0] == util.bits(ref["t"])[0]
+    for mode in (api.PT_TRACE_FAST, api.PT_TRACE_FAST_BINARY):
+        got = ds.trace_closest(o, d, mode)
+        # the hit that is really there (with the default tree and settings), or the reference's when the walk
+        # happens to open that leaf first (other leaf sizes or child orders)
+        real = got["tri"][0] == 3275 and abs(float(got["t"][0]) - 0.9713243) < 1e-6
+        noise = got["tri"][0] == 1395 and util.bits(got["t"])[0] == util.bits(ref["t"])[0]
+        assert real or noise
+
