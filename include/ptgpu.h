@@ -148,7 +148,7 @@ enum { PT_SAMPLE_UNIFORM = 0, PT_SAMPLE_COSINE = 1 };
  * One known deviation of the pruning modes: a ray lying in a triangle's plane to within rounding can make the
  * reference's triangle test report a hit at a distance unrelated to the triangle (its determinant is noise);
  * when that distance is nearer than the true closest hit, a walk that prunes by distance does not see it
- * (measured: 2 of 28 million rays aimed at vertices).  PT_TRACE_EXACT reproduces those hits too. */
+ * (measured: 3 of 68 million rays aimed at vertices).  PT_TRACE_EXACT reproduces those hits too. */
 enum { PT_TRACE_EXACT = 0, PT_TRACE_FAST = 1, PT_TRACE_FAST_BINARY = 2 };
 
 /* Integrator constants.  pt_options_default() fills in the reference literals
